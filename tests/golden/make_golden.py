@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python modules on CPU.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are committed, this script is the provenance record.  Nothing from the
+reference is copied: its modules are imported where they lie, driven with
+seeded random weights (the trained checkpoint is not available offline) and
+their inputs/outputs are saved as data.
+
+Shims: stub modules for the mesh-only native libs and
+``trimesh`` (imported eagerly by src/conv_onet/__init__.py), a ``torch_scatter``
+stand-in (torch-scatter 2.0.5 is not installed), and a no-op ``Tensor.cuda``.
+``opt_defense.py`` itself is not importable (argparse + torch.load + cuda at
+import time), so its 30-line ``optimize_points`` loop is driven from here with
+the reference's ``model.decode`` / ``repulsion_loss`` / ``torch.optim.Adam``.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/ConvONet"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+# ----------------------------------------------------------------- shims
+for name, attrs in [("trimesh", {}), ("src.utils.libmcubes", {}),
+                    ("src.utils.libsimplify", {"simplify_mesh": None}),
+                    ("src.utils.libmise", {"MISE": None})]:
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+
+ts = types.ModuleType("torch_scatter")
+
+
+def _scatter_max(src, index, dim_size=None, **kw):
+    idx = index.expand(src.shape[0], src.shape[1], -1)
+    out = src.new_zeros(src.shape[0], src.shape[1], dim_size)
+    out = out.scatter_reduce(2, idx, src, reduce="amax", include_self=False)
+    return out, None
+
+
+def _scatter_mean(src, index, out=None, **kw):
+    idx = index.expand(src.shape[0], src.shape[1], -1)
+    summed = out.scatter_add(2, idx, src)
+    cnt = torch.zeros_like(out).scatter_add(2, idx, torch.ones_like(src))
+    return summed / cnt.clamp(min=1)
+
+
+ts.scatter_max, ts.scatter_mean = _scatter_max, _scatter_mean
+sys.modules["torch_scatter"] = ts
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+from src.encoder.pointnet import LocalPoolPointnet            # noqa: E402
+from src.conv_onet.models.decoder import LocalDecoder         # noqa: E402
+from src.conv_onet.models import ConvolutionalOccupancyNetwork  # noqa: E402
+from defense import SORDefense, repulsion_loss                # noqa: E402
+from defense.pn_utils import knn_point                        # noqa: E402
+
+from oracle import convonet_oracle as O                       # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+WEIGHT_SEED = 0
+
+
+def build_reference_model():
+    enc = LocalPoolPointnet(c_dim=32, dim=3, hidden_dim=32, scatter_type="max", unet=True,
+                            unet_kwargs=dict(depth=4, merge_mode="concat", start_filts=32),
+                            plane_resolution=64, plane_type=["xz", "xy", "yz"], padding=0.1)
+    dec = LocalDecoder(dim=3, c_dim=32, hidden_size=32, sample_mode="bilinear", padding=0.1)
+    model = ConvolutionalOccupancyNetwork(dec, enc, device=torch.device("cpu"))
+    sd = {k: torch.from_numpy(v) for k, v in O.make_random_weights(WEIGHT_SEED).items()}
+    missing = model.load_state_dict(sd, strict=True)
+    print("load_state_dict:", missing)
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+# ----------------------------------------------------------------- inputs
+def synth_clouds(rng):
+    """4 raw 1024-point clouds, unit-sphere normalised like ModelNet40 inputs."""
+    def norm(pc):
+        pc = pc - pc.mean(0)
+        return (pc / np.linalg.norm(pc, axis=1).max()).astype(np.float32)
+
+    air = np.load("/root/reference/baselines/data/airplane.npy").astype(np.float32)  # data file, [1024,3]
+    v = rng.standard_normal((1024, 3))
+    sphere = v / np.linalg.norm(v, axis=1, keepdims=True)
+    sphere[:40] *= rng.uniform(1.05, 1.6, size=(40, 1))            # outliers for SOR to remove
+    a, b = rng.uniform(0, 2 * np.pi, (2, 1024))
+    torus = np.stack([(1 + 0.35 * np.cos(b)) * np.cos(a), (1 + 0.35 * np.cos(b)) * np.sin(a),
+                      0.35 * np.sin(b)], 1) + rng.normal(0, 0.01, (1024, 3))
+    face = rng.integers(0, 6, 1024)
+    box = rng.uniform(-1, 1, (1024, 3)) * np.array([1.0, 0.6, 0.4])
+    ax = face // 2
+    box[np.arange(1024), ax] = np.where(face % 2 == 0, 1, -1) * np.array([1.0, 0.6, 0.4])[ax]
+    return np.stack([norm(air), norm(sphere), norm(torus), norm(box)])
+
+
+def ref_preprocess(pc, padding_scale=0.9):
+    """numpy lines of opt_defense.preprocess_pc (:122-127); the random subset is drawn by the caller."""
+    center = np.mean(pc, axis=0)
+    centered = pc - center
+    scale = (np.max(centered, axis=0) - np.min(centered, axis=0)).max()
+    return centered / scale * padding_scale
+
+
+def ref_optimize(model, init, planes, iterations, rep_weight=500.0, lr=1e-3, threshold=0.2, record=()):
+    """The loop of opt_defense.optimize_points (:198-238) around the reference model + loss."""
+    import torch.nn.functional as F
+    x = init.clone().float()
+    x.requires_grad_()
+    B, K = x.shape[:2]
+    target = torch.ones((B, K)).float() * threshold
+    opt = torch.optim.Adam([x], lr=lr)
+    snaps = {}
+    for i in range(iterations + 1):
+        occ_value = model.decode(x, planes).logits
+        occ_loss = F.binary_cross_entropy_with_logits(occ_value, target, reduction="none")
+        occ_loss = torch.mean(occ_loss) * K
+        rep_loss = torch.mean(repulsion_loss(x)) * rep_weight
+        loss = occ_loss + rep_loss
+        opt.zero_grad()
+        loss.backward()
+        if i in record:
+            st = opt.state[x]
+            snaps[i] = dict(x=x.detach().clone(), g=x.grad.detach().clone(),
+                            m=st["exp_avg"].clone() if st else torch.zeros_like(x),
+                            v=st["exp_avg_sq"].clone() if st else torch.zeros_like(x),
+                            occ=float(occ_loss), rep=float(rep_loss))
+        opt.step()
+        if i in record:
+            snaps[i]["x_next"] = x.detach().clone()
+    return x.detach(), snaps
+
+
+def ref_normalize(points):
+    centroid = torch.mean(points, dim=1)
+    points = points - centroid[:, None, :]
+    dist = torch.sum(points ** 2, dim=2) ** 0.5
+    return points / torch.max(dist, dim=1)[0][:, None, None]
+
+
+def main():
+    rng = np.random.default_rng(1234)
+    model = build_reference_model()
+    out = {}
+    raw = synth_clouds(rng)                                        # [4,1024,3]
+    out["raw"] = raw
+
+    # G5: SOR (reference SORDefense, fp64 internally)
+    sor = SORDefense(k=2, alpha=1.1)
+    kept = sor(torch.from_numpy(raw))
+    keep_mask = np.zeros((4, 1024), bool)
+    # recompute the mask + value through the reference's own lines (outlier_removal returns only points)
+    pc64 = torch.from_numpy(raw).double().transpose(2, 1)
+    inner = -2. * torch.matmul(pc64.transpose(2, 1), pc64)
+    xx = torch.sum(pc64 ** 2, dim=1, keepdim=True)
+    dist = xx + inner + xx.transpose(2, 1)
+    neg_value, _ = (-dist).topk(k=3, dim=-1)
+    value = torch.mean(-(neg_value[..., 1:]), dim=-1)
+    thr = torch.mean(value, dim=-1) + 1.1 * torch.std(value, dim=-1)
+    keep_mask = (value <= thr[:, None]).numpy()
+    for b in range(4):
+        assert np.array_equal(raw[b][keep_mask[b]], kept[b].numpy()), "mask does not reproduce SORDefense output"
+    out["sor_keep"] = keep_mask
+    out["sor_value"] = value.numpy()
+    print("SOR kept:", keep_mask.sum(1))
+
+    # G6: preprocess (+ recorded random draws: 600-subset, 1024 init indices, N(0,1) noise)
+    proc, sel_idx, init_idx = [], [], []
+    for b in range(4):
+        pts = ref_preprocess(raw[b][keep_mask[b]])
+        proc.append(pts.astype(np.float32))
+        sel_idx.append(rng.choice(len(pts), 600, replace=False))
+        init_idx.append(rng.integers(0, len(pts), 1024))
+    noise = rng.standard_normal((4, 1024, 3)).astype(np.float32)
+    lens = np.array([len(p) for p in proc])
+    proc_pad = np.zeros((4, 1024, 3), np.float32)
+    for b in range(4):
+        proc_pad[b, :lens[b]] = proc[b]
+    out.update(proc_len=lens, proc_pad=proc_pad, sel_idx=np.stack(sel_idx), init_idx=np.stack(init_idx),
+               noise=noise)
+    sel = torch.from_numpy(np.stack([proc[b][sel_idx[b]] for b in range(4)]))      # [4,600,3]
+
+    # G1: encoder stages (reference LocalPoolPointnet)
+    enc = model.encoder
+    with torch.no_grad():
+        planes = model.encode_inputs(sel)
+        # point features c (re-run the point-wise part through the reference's own methods)
+        from src.common import normalize_coordinate, coordinate2index
+        coord = {pl: normalize_coordinate(sel.clone(), plane=pl, padding=0.1) for pl in ("xz", "xy", "yz")}
+        index = {pl: coordinate2index(coord[pl], 64) for pl in coord}
+        net = enc.blocks[0](enc.fc_pos(sel))
+        stage0 = net.clone()
+        for blk in enc.blocks[1:]:
+            pooled = enc.pool_local(coord, index, net)
+            net = blk(torch.cat([net, pooled], dim=2))
+        c_pts = enc.fc_c(net)
+        fea = c_pts.new_zeros(4, 32, 64 * 64)
+        pre_xz = ts.scatter_mean(c_pts.permute(0, 2, 1), index["xz"], out=fea).reshape(4, 32, 64, 64)
+    out["enc_index"] = np.stack([index[pl][:, 0].numpy() for pl in ("xz", "xy", "yz")], 1).astype(np.int32)
+    out["enc_stage0"] = stage0[:2].numpy()
+    out["enc_c"] = c_pts.numpy()
+    out["enc_pre_xz0"] = pre_xz[0].numpy()
+    out["planes01"] = np.stack([planes[pl][:2].numpy() for pl in ("xz", "xy", "yz")], 1)   # [2,3,32,64,64]
+    out["planes_stats"] = np.stack([[float(planes[pl][b].mean()), float(planes[pl][b].abs().mean())]
+                                    for b in range(4) for pl in ("xz", "xy", "yz")]).reshape(4, 3, 2)
+
+    # init points (reference init_points lines :169-178 with the recorded draws)
+    pts0 = torch.stack([torch.from_numpy(proc[b])[torch.from_numpy(init_idx[b])] for b in range(4)])
+    pts0 = torch.clamp(pts0 + torch.from_numpy(noise) * 0.01, min=-0.45, max=0.45)
+    out["init_points"] = pts0.numpy()
+
+    # G2: decoder logits + d(sum logits)/dp on clouds 0,1
+    p2 = pts0[:2].clone().requires_grad_()
+    planes2 = {pl: planes[pl][:2] for pl in planes}
+    logits = model.decode(p2, planes2).logits
+    logits.sum().backward()
+    out["dec_logits"] = logits.detach().numpy()
+    out["dec_dlogit_dp"] = p2.grad.numpy().copy()
+
+    # G3: losses + kNN + total gradient at B=2 (natural 1/B) on clouds 0,1
+    idx = knn_point(5, pts0[:2])
+    out["knn_idx"] = idx.numpy().astype(np.int32)
+    with torch.no_grad():
+        out["rep_loss_b"] = repulsion_loss(pts0[:2]).numpy()
+
+    # G3/G4/G7: trajectory snapshots incl. Adam state for teacher-forced single steps (B=2)
+    rec = (0, 1, 9, 49)
+    xT, snaps = ref_optimize(model, pts0[:2], planes2, iterations=50, record=rec)
+    for i in rec:
+        s = snaps[i]
+        for k in ("x", "g", "m", "v", "x_next"):
+            out[f"traj{i}_{k}"] = s[k].numpy()
+        out[f"traj{i}_loss"] = np.array([s["occ"], s["rep"]], np.float64)
+    out["traj_final51"] = xT.numpy()
+
+    # G8: end to end on all 4 clouds, iterations=20 (21 steps), B=4, normalised output
+    x20, _ = ref_optimize(model, pts0, planes, iterations=20)
+    out["e2e20_out"] = ref_normalize(x20).numpy()
+
+    # self-divergence floor of the reference under a 1-ulp perturbation (context for P2/P3)
+    pert = pts0[:2] * (1 + 1e-7)
+    xp, _ = ref_optimize(model, pert, planes2, iterations=50)
+    d = (xp - xT).norm(dim=-1)
+    out["selfdiv51"] = np.array([float(d.max()), float(d.mean()), float((d > 1e-3).float().mean())])
+    print("self-divergence @51 steps: max %.3e mean %.3e frac>1e-3 %.3f" % tuple(out["selfdiv51"]))
+
+    path = os.path.join(HERE, "convonet_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

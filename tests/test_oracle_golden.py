@@ -1,0 +1,137 @@
+"""Pin the CPU oracle (oracle/) against outputs of the reference's own modules.
+
+The fixtures in tests/golden/convonet_golden.npz were produced by
+tests/golden/make_golden.py, which imports /root/reference/ConvONet on CPU.
+Tolerances are float32 round-off: both sides run torch CPU kernels, but op
+ordering (e.g. torch.where vs masked assignment, scatter order) may differ.
+"""
+import numpy as np
+import torch
+
+from oracle import closed_form as CF
+from oracle import convonet_oracle as O
+
+PL = ("xz", "xy", "yz")
+
+
+def _planes(golden, n=2):
+    return {pl: torch.from_numpy(golden["planes01"][:n, i]) for i, pl in enumerate(PL)}
+
+
+def _proc(golden):
+    return [golden["proc_pad"][b, :golden["proc_len"][b]] for b in range(4)]
+
+
+def test_sor_mask_and_value(golden):
+    keep, value = O.sor_keep_mask(torch.from_numpy(golden["raw"]))
+    assert np.array_equal(keep.numpy(), golden["sor_keep"])            # bit-exact mask
+    np.testing.assert_allclose(value.numpy(), golden["sor_value"], rtol=1e-12, atol=0)
+    assert golden["sor_keep"].sum(1).tolist() == [909, 999, 885, 906]
+
+
+def test_preprocess(golden):
+    for b in range(4):
+        got = O.preprocess_pc(golden["raw"][b][golden["sor_keep"][b]])
+        np.testing.assert_array_equal(got, _proc(golden)[b])           # same numpy f32 ops
+
+
+def test_init_points(golden):
+    got = O.init_points(_proc(golden), golden["init_idx"], golden["noise"])
+    np.testing.assert_array_equal(got.numpy(), golden["init_points"])
+
+
+def test_encoder_pointnet(golden, oracle_weights):
+    proc = _proc(golden)
+    sel = torch.from_numpy(np.stack([proc[b][golden["sel_idx"][b]] for b in range(4)]))
+    c, index, stages = O.pointnet_features(oracle_weights, sel, return_stages=True)
+    got_index = np.stack([index[pl].numpy() for pl in PL], 1)
+    assert np.array_equal(got_index, golden["enc_index"])
+    np.testing.assert_allclose(stages[0][:2].numpy(), golden["enc_stage0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c.numpy(), golden["enc_c"], rtol=1e-4, atol=2e-6)
+    pre = O.scatter_mean_plane(c, index["xz"])
+    np.testing.assert_allclose(pre[0].numpy(), golden["enc_pre_xz0"], rtol=1e-4, atol=2e-6)
+
+
+def test_encoder_planes(golden, oracle_weights):
+    proc = _proc(golden)
+    sel = torch.from_numpy(np.stack([proc[b][golden["sel_idx"][b]] for b in range(4)]))
+    planes = O.encode_inputs(oracle_weights, sel)
+    for i, pl in enumerate(PL):
+        ref = golden["planes01"][:, i]
+        np.testing.assert_allclose(planes[pl][:2].numpy(), ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max())
+        for b in range(4):
+            assert abs(float(planes[pl][b].abs().mean()) - golden["planes_stats"][b, i, 1]) < 1e-5
+
+
+def test_decoder_logits_and_grad(golden, oracle_weights):
+    p = torch.from_numpy(golden["init_points"][:2]).clone().requires_grad_()
+    logits = O.decode_logits(oracle_weights, p, _planes(golden))
+    logits.sum().backward()
+    np.testing.assert_allclose(logits.detach().numpy(), golden["dec_logits"], rtol=1e-5, atol=1e-6)
+    ref = golden["dec_dlogit_dp"]
+    np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_knn_and_repulsion(golden):
+    p = torch.from_numpy(golden["init_points"][:2])
+    idx = O.knn_point(5, p)
+    assert np.array_equal(idx.numpy(), golden["knn_idx"])
+    np.testing.assert_allclose(O.repulsion_loss(p).numpy(), golden["rep_loss_b"], rtol=1e-5)
+    # the exact float64 direct-form neighbour SETS agree with the reference's f32 expanded form
+    for b in range(2):
+        ex = CF.knn_exact(golden["init_points"][b])
+        same = [set(ex[i]) == set(golden["knn_idx"][b, i]) for i in range(1024)]
+        assert np.mean(same) > 0.995
+
+
+def test_total_gradient_and_losses(golden, oracle_weights):
+    for step in (0, 1, 9, 49):
+        x = torch.from_numpy(golden[f"traj{step}_x"]).clone().requires_grad_()
+        total, occ, rep, _ = O.losses(oracle_weights, x, _planes(golden), 500.0)
+        total.backward()
+        ref = golden[f"traj{step}_g"]
+        np.testing.assert_allclose(x.grad.numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max())
+        np.testing.assert_allclose([float(occ.detach()), float(rep.detach())], golden[f"traj{step}_loss"], rtol=1e-5)
+
+
+def test_closed_form_matches_reference_gradient(golden, np_weights):
+    """float64 hand-derived backward == the reference's autograd gradient."""
+    for step in (0, 9):
+        x = golden[f"traj{step}_x"]
+        ref = golden[f"traj{step}_g"]
+        for b in range(2):
+            planes = {pl: golden["planes01"][b, i] for i, pl in enumerate(PL)}
+            d = CF.decoder_forward_backward(np_weights, x[b], planes, loss_batch=2.0)
+            idx = O.knn_point(5, torch.from_numpy(x[b:b + 1]))[0].numpy()
+            r = CF.repulsion_forward_backward(x[b], idx=idx, loss_batch=2.0)
+            g = d["grad"] + r["grad"]
+            err = np.abs(g - ref[b]).max() / np.abs(ref[b]).max()
+            assert err < 2e-5, err
+
+
+def test_adam_teacher_forced(golden):
+    for step in (0, 1, 9, 49):
+        x, g = (torch.from_numpy(golden[f"traj{step}_{k}"]) for k in ("x", "g"))
+        m, v = (torch.from_numpy(golden[f"traj{step}_{k}"]) for k in ("m", "v"))
+        x1, _, _ = O.adam_step(x, g, m, v, t=step + 1)
+        np.testing.assert_allclose(x1.numpy(), golden[f"traj{step}_x_next"], rtol=0, atol=2e-7)
+
+
+def test_trajectory_short_horizon(golden, oracle_weights):
+    init = torch.from_numpy(golden["init_points"][:2])
+    _, snaps = O.optimize_points(oracle_weights, init, _planes(golden), iterations=9, normalize=False,
+                                 record=(1, 2, 10))
+    for n, key in ((1, "traj0_x_next"), (2, "traj1_x_next"), (10, "traj9_x_next")):
+        d = (snaps[n] - torch.from_numpy(golden[key])).norm(dim=-1)
+        assert float(d.max()) < 1e-3, (n, float(d.max()))
+    assert float((snaps[1] - torch.from_numpy(golden["traj0_x_next"])).abs().max()) < 1e-6
+
+
+def test_end_to_end_20(golden, oracle_weights):
+    init = torch.from_numpy(golden["init_points"])
+    planes4 = O.encode_inputs(oracle_weights, torch.from_numpy(
+        np.stack([_proc(golden)[b][golden["sel_idx"][b]] for b in range(4)])))
+    out = O.optimize_points(oracle_weights, init, planes4, iterations=20)
+    d = (out - torch.from_numpy(golden["e2e20_out"])).norm(dim=-1)
+    # 21 chaotic steps: bulk must agree tightly, a few points may have diverged
+    assert float(d.median()) < 1e-4 and float((d > 1e-2).float().mean()) < 0.01, (float(d.median()), float(d.max()))
