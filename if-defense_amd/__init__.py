@@ -1,0 +1,12 @@
+"""if-defense_amd: MI355X-native ConvONet-Opt restoration (IF-Defense hot path).
+
+Import name: ``ifdefense_amd`` (see the shim at the repo root).  Importing the package does not load
+the HIP library; constructing a ``Restorer`` (or calling ``load_library``) does, and fails loudly when
+``csrc/libifd.so`` is absent - there is no CPU fallback.
+"""
+from . import weights            # noqa: F401
+from ._lib import LIB_PATH, load as load_library   # noqa: F401
+from .runtime import IfdError, Restorer, planes_from_channel_last, planes_to_channel_last   # noqa: F401
+
+__all__ = ["Restorer", "IfdError", "weights", "load_library", "LIB_PATH", "planes_to_channel_last",
+           "planes_from_channel_last"]

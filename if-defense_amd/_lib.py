@@ -1,0 +1,67 @@
+"""ctypes binding of libifd.so (the C ABI in include/ifd.h).
+
+The product path has NO fallback: if the HIP library is missing or does not load, importing
+this module raises.  (The CPU oracle under oracle/ is test infrastructure and is never used here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libifd.so")
+
+IFD_OK = 0
+ABI_VERSION = 1
+
+
+class IfdConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("plane_resolution", C.c_int32), ("c_dim", C.c_int32),
+                ("hidden_dim", C.c_int32), ("n_blocks", C.c_int32), ("unet_depth", C.c_int32),
+                ("unet_start_filts", C.c_int32), ("padding", C.c_float)]
+
+
+class IfdOptParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("steps", C.c_int32), ("t0", C.c_int32),
+                ("loss_batch", C.c_int32), ("normalize", C.c_int32), ("lr", C.c_float),
+                ("rep_weight", C.c_float), ("threshold", C.c_float), ("rep_radius", C.c_float),
+                ("rep_h", C.c_float), ("rep_eps", C.c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol include/ifd.h declares (tests check this)
+SIGNATURES = {
+    "ifd_abi_version": (C.c_int, []),
+    "ifd_weight_count": (C.c_size_t, []),
+    "ifd_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(IfdConfig), C.c_int]),
+    "ifd_destroy": (None, [C.c_void_p]),
+    "ifd_last_error": (C.c_char_p, [C.c_void_p]),
+    "ifd_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
+    "ifd_repulsion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    "ifd_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ifd_normalize_unit_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libifd.so (after torch, so both share one HIP runtime) and bind every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libifd.so is not built (%s). Run `python if-defense_amd/build.py` (needs hipcc); "
+            "there is no CPU or PyTorch fallback for the restoration path." % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first; libifd binds to the same runtime)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.ifd_abi_version() != ABI_VERSION:
+        raise ImportError("libifd.so ABI %d != binding ABI %d; rebuild" % (lib.ifd_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib

@@ -1,0 +1,216 @@
+// C ABI of libifd.so (see include/ifd.h).  Host-side only: context, weight re-packing, argument
+// validation and kernel launches.  Never throws, never exits, never synchronises the device.
+#include "../../include/ifd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ifd_internal.h"
+
+using namespace ifd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// Offsets (in floats) of every tensor in the canonical weight order documented in ifd.h.
+struct WeightMap {
+    size_t dec_fc_p_w, dec_fc_p_b, dec_fc_c_w[5], dec_fc_c_b[5];
+    size_t dec_fc0_w[5], dec_fc0_b[5], dec_fc1_w[5], dec_fc1_b[5], dec_out_w, dec_out_b;
+    size_t enc_pos_w, enc_pos_b, enc_fc0_w[5], enc_fc0_b[5], enc_fc1_w[5], enc_fc1_b[5], enc_sc_w[5];
+    size_t enc_fcc_w, enc_fcc_b;
+    size_t down_w[4][2], down_b[4][2];
+    size_t up_t_w[3], up_t_b[3], up_w[3][2], up_b[3][2], fin_w, fin_b;
+    size_t total;
+};
+
+WeightMap make_weight_map() {
+    WeightMap m{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += n; return r; };
+    m.dec_fc_p_w = take(32 * 3); m.dec_fc_p_b = take(32);
+    for (int i = 0; i < 5; ++i) { m.dec_fc_c_w[i] = take(1024); m.dec_fc_c_b[i] = take(32); }
+    for (int i = 0; i < 5; ++i) {
+        m.dec_fc0_w[i] = take(1024); m.dec_fc0_b[i] = take(32);
+        m.dec_fc1_w[i] = take(1024); m.dec_fc1_b[i] = take(32);
+    }
+    m.dec_out_w = take(32); m.dec_out_b = take(1);
+    m.enc_pos_w = take(64 * 3); m.enc_pos_b = take(64);
+    for (int i = 0; i < 5; ++i) {
+        m.enc_fc0_w[i] = take(32 * 64); m.enc_fc0_b[i] = take(32);
+        m.enc_fc1_w[i] = take(32 * 32); m.enc_fc1_b[i] = take(32);
+        m.enc_sc_w[i] = take(32 * 64);
+    }
+    m.enc_fcc_w = take(1024); m.enc_fcc_b = take(32);
+    const int ch[4] = {32, 64, 128, 256};
+    int cin = 32;
+    for (int i = 0; i < 4; ++i) {
+        m.down_w[i][0] = take((size_t)ch[i] * cin * 9); m.down_b[i][0] = take(ch[i]);
+        m.down_w[i][1] = take((size_t)ch[i] * ch[i] * 9); m.down_b[i][1] = take(ch[i]);
+        cin = ch[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        const int co = cin / 2;
+        m.up_t_w[i] = take((size_t)cin * co * 4); m.up_t_b[i] = take(co);
+        m.up_w[i][0] = take((size_t)co * 2 * co * 9); m.up_b[i][0] = take(co);
+        m.up_w[i][1] = take((size_t)co * co * 9); m.up_b[i][1] = take(co);
+        cin = co;
+    }
+    m.fin_w = take(32 * 32); m.fin_b = take(32);
+    m.total = o;
+    return m;
+}
+
+const WeightMap& wmap() {
+    static const WeightMap m = make_weight_map();
+    return m;
+}
+
+}  // namespace
+
+struct ifd_ctx {
+    int device = 0;
+    ifd_config cfg{};
+    std::vector<float> w;          // host copy, canonical order
+    float* d_dec_img = nullptr;    // decoder parameter image (ifd_device.h layout)
+    DecConst dc{};
+    std::string err;
+};
+
+namespace {
+
+int fail(ifd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+// Build the LDS image of the decoder parameters.
+std::vector<float> build_dec_image(const float* w) {
+    const WeightMap& m = wmap();
+    std::vector<float> img(DEC_FLOATS, 0.f);
+    auto put_layer = [&](int L, size_t woff, size_t boff) {
+        for (int o = 0; o < 32; ++o)
+            for (int k = 0; k < 32; ++k) img[DEC_OFF_W + L * W_LAYER + o * W_STRIDE + k] = w[woff + o * 32 + k];
+        for (int o = 0; o < 32; ++o) img[DEC_OFF_BIAS + L * 32 + o] = w[boff + o];
+    };
+    for (int i = 0; i < 5; ++i) {
+        put_layer(3 * i + 0, m.dec_fc_c_w[i], m.dec_fc_c_b[i]);
+        put_layer(3 * i + 1, m.dec_fc0_w[i], m.dec_fc0_b[i]);
+        put_layer(3 * i + 2, m.dec_fc1_w[i], m.dec_fc1_b[i]);
+    }
+    for (int c = 0; c < 32; ++c) {
+        for (int a = 0; a < 3; ++a) img[DEC_OFF_WP + c * 4 + a] = w[m.dec_fc_p_w + c * 3 + a];
+        img[DEC_OFF_WP + c * 4 + 3] = w[m.dec_fc_p_b + c];
+        img[DEC_OFF_WOUT + c] = w[m.dec_out_w + c];
+    }
+    img[DEC_OFF_BOUT] = w[m.dec_out_b];
+    return img;
+}
+
+bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > MAXK; }
+
+}  // namespace
+
+extern "C" {
+
+int ifd_abi_version(void) { return IFD_ABI_VERSION; }
+
+size_t ifd_weight_count(void) { return wmap().total; }
+
+const char* ifd_last_error(const ifd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_config* cfg, int device) {
+    g_create_error.clear();
+    if (!weights_host || !cfg) { g_create_error = "ifd_create: NULL argument"; return nullptr; }
+    if (n_weights != wmap().total) {
+        g_create_error = "ifd_create: expected " + std::to_string(wmap().total) + " weights, got " +
+                         std::to_string(n_weights);
+        return nullptr;
+    }
+    if (cfg->struct_size != (int32_t)sizeof(ifd_config) || cfg->plane_resolution != RES || cfg->c_dim != CH ||
+        cfg->hidden_dim != CH || cfg->n_blocks != NBLK || cfg->unet_depth != 4 || cfg->unet_start_filts != 32) {
+        g_create_error = "ifd_create: only the shipped 3-plane config (res 64, c_dim 32, hidden 32, 5 blocks, "
+                         "U-Net depth 4 / 32 filters) is supported";
+        return nullptr;
+    }
+    ifd_ctx* ctx = new (std::nothrow) ifd_ctx();
+    if (!ctx) { g_create_error = "ifd_create: out of host memory"; return nullptr; }
+    ctx->device = device;
+    ctx->cfg = *cfg;
+    ctx->w.assign(weights_host, weights_host + n_weights);
+    ctx->dc.sdiv = (float)(1.0 + (double)cfg->padding + 10e-6);
+    ctx->dc.uclamp = (float)(1.0 - 10e-6);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_dec_img), DEC_FLOATS * sizeof(float));
+    if (e == hipSuccess) {
+        std::vector<float> img = build_dec_image(ctx->w.data());
+        e = hipMemcpy(ctx->d_dec_img, img.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = configure_optimize_kernels();
+    if (e != hipSuccess) {
+        g_create_error = std::string("ifd_create: ") + hipGetErrorString(e);
+        if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void ifd_destroy(ifd_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
+    delete ctx;
+}
+
+int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,
+               void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!planes || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_decode: bad argument");
+    hipError_t e = launch_decode(ctx->d_dec_img, planes, p, B, K, logits, dlogit_dp, ctx->dc,
+                                 static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_decode launch", e);
+}
+
+int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx,
+                  void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!p || !loss || bad_bk(B, K)) return fail(ctx, IFD_ERR_ARG, "ifd_repulsion: bad argument (6 <= K <= 1024)");
+    hipError_t e = launch_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f,
+                                    static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_repulsion launch", e);
+}
+
+int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, const ifd_opt_params* prm, float* m,
+                 float* v, float* loss, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 1024)");
+    if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: pass both m and v or neither");
+    if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
+    OptArgs a;
+    a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
+    a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
+    a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
+    a.dc = ctx->dc;
+    hipError_t e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, B, K, a, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
+}
+
+int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!p || B < 1 || K < 1 || K > MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument");
+    hipError_t e = launch_normalize(p, B, K, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_normalize launch", e);
+}
+
+}  // extern "C"

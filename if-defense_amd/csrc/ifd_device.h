@@ -1,0 +1,40 @@
+// Shared device-side definitions for libifd (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ifd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RES = 64;              // plane resolution
+constexpr int CH = 32;               // c_dim == hidden
+constexpr int NBLK = 5;
+constexpr int PLANE_FLOATS = RES * RES * CH;        // one plane, channel-last
+constexpr int CLOUD_PLANE_FLOATS = 3 * PLANE_FLOATS; // 1.5 MiB / cloud
+
+// ---- decoder parameter image (identical in global memory and in LDS) -------------
+// W[15][32][33]: layer L = 3*i + j (j: 0 fc_c[i], 1 blocks[i].fc_0, 2 blocks[i].fc_1), row = out
+// channel, col = in channel, row stride padded to 33 floats so that both the row-gather (forward,
+// A[o][k]) and the column-gather (backward, A = W^T) are conflict-free ds_read_b32 patterns.
+constexpr int W_STRIDE = 33;
+constexpr int W_LAYER = 32 * W_STRIDE;               // 1056
+constexpr int DEC_OFF_W = 0;
+constexpr int DEC_OFF_BIAS = 15 * W_LAYER;           // 15840: [15][32]
+constexpr int DEC_OFF_WP = DEC_OFF_BIAS + 15 * 32;   // 16320: [32][4] = {Wp[ch][0..2], bp[ch]}
+constexpr int DEC_OFF_WOUT = DEC_OFF_WP + 32 * 4;    // 16448: [32]
+constexpr int DEC_OFF_BOUT = DEC_OFF_WOUT + 32;      // 16480: [1] (+3 pad)
+constexpr int DEC_FLOATS = DEC_OFF_BOUT + 4;         // 16484 floats = 65,936 B
+
+constexpr int MAXK = 1024;           // points per cloud held in LDS
+constexpr int OPT_THREADS = 512;     // 8 waves: 2 per SIMD
+constexpr float FIX_SCALE = 1099511627776.0f;        // 2^40: fixed-point scale of the neighbour scatter
+constexpr float FIX_INV = 1.0f / 1099511627776.0f;
+
+struct DecConst {
+    float sdiv;      // (float)(1 + padding + 10e-6)           common.py:250
+    float uclamp;    // (float)(1 - 10e-6)                     common.py:255
+};
+
+}  // namespace ifd

@@ -1,0 +1,24 @@
+// Host-side internal interface between the C ABI (api.cpp) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ifd_device.h"
+
+namespace ifd {
+
+struct OptArgs {
+    int steps, t0, loss_batch, normalize;
+    float lr, rep_weight, threshold, rep_radius, rep_h, rep_eps;
+    DecConst dc;
+};
+
+hipError_t configure_optimize_kernels();
+hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
+                           int B, int K, const OptArgs& a, hipStream_t s);
+hipError_t launch_decode(const float* dec_img, const float* planes, const float* p, int B, int K, float* logits,
+                         float* dlogit_dp, DecConst dc, hipStream_t s);
+hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
+                            float h, float eps, hipStream_t s);
+hipError_t launch_normalize(float* p, int B, int K, hipStream_t s);
+
+}  // namespace ifd

@@ -1,0 +1,153 @@
+"""Host-side mirror of the reference's call seams for the ConvONet-Opt path.
+
+The reference exposes the path through module-level globals (``generator.model.encode_inputs`` /
+``.decode`` / ``repulsion_loss`` / ``optimize_points``, ConvONet/opt_defense.py:212,221,300,182).
+``Restorer`` offers the same calls with the same argument meaning, backed by libifd.so's HIP kernels;
+PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import IfdConfig, IfdOptParams
+
+PLANE_ORDER = ("xz", "xy", "yz")
+
+
+class IfdError(RuntimeError):
+    pass
+
+
+def planes_to_channel_last(planes: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Reference layout {'xz','xy','yz': [B,32,64,64]} -> device layout [B,3,64,64,32] (include/ifd.h)."""
+    return torch.stack([planes[k] for k in PLANE_ORDER], dim=1).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def planes_from_channel_last(planes: torch.Tensor) -> Dict[str, torch.Tensor]:
+    return {k: planes[:, i].permute(0, 3, 1, 2).contiguous() for i, k in enumerate(PLANE_ORDER)}
+
+
+def _f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Restorer:
+    """One context = one model on one GPU (ifd_create ... ifd_destroy)."""
+
+    def __init__(self, weights: np.ndarray, device=None, padding: float = 0.1, threshold: float = 0.2):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise IfdError("no GPU visible: the restoration path only runs on an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise IfdError("Restorer needs a cuda (ROCm) device, got %s" % self.device)
+        self.threshold = float(threshold)
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        if w.size != self.lib.ifd_weight_count():
+            raise IfdError("expected %d weights, got %d" % (self.lib.ifd_weight_count(), w.size))
+        cfg = IfdConfig(C.sizeof(IfdConfig), 64, 32, 32, 5, 4, 32, float(padding))
+        with torch.cuda.device(self.device):
+            self.ctx = self.lib.ifd_create(w.ctypes.data, w.size, C.byref(cfg), self.device.index or 0)
+        if not self.ctx:
+            raise IfdError((self.lib.ifd_last_error(None) or b"ifd_create failed").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ifd_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    # ---------------------------------------------------------------- helpers
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check(self, rc: int):
+        if rc != _lib.IFD_OK:
+            raise IfdError("libifd error %d: %s" % (rc, (self.lib.ifd_last_error(self.ctx) or b"").decode()))
+
+    @staticmethod
+    def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+        return None if t is None else t.data_ptr()
+
+    def _planes(self, c) -> torch.Tensor:
+        if isinstance(c, dict):
+            c = planes_to_channel_last({k: _f32(v, self.device) for k, v in c.items()})
+        c = _f32(c, self.device)
+        if c.dim() != 5 or tuple(c.shape[1:]) != (3, 64, 64, 32):
+            raise IfdError("planes must be [B,3,64,64,32] channel-last or the reference's dict of [B,32,64,64]")
+        return c
+
+    # ---------------------------------------------------------------- call seams
+    def decode(self, p: torch.Tensor, c, want_grad: bool = False):
+        """generator.model.decode(p, c).logits -> [B,K]; with want_grad also d(sum logits)/dp [B,K,3]."""
+        planes = self._planes(c)
+        p = _f32(p, self.device)
+        B, K = p.shape[:2]
+        logits = torch.empty(B, K, device=self.device, dtype=torch.float32)
+        grad = torch.empty(B, K, 3, device=self.device, dtype=torch.float32) if want_grad else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_decode(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, logits.data_ptr(),
+                                            self._ptr(grad), self._stream()))
+        return (logits, grad) if want_grad else logits
+
+    def repulsion_loss(self, p: torch.Tensor, want_grad: bool = False, want_idx: bool = False):
+        """repulsion_loss(p) -> [B] (defense/repulsion_loss.py:18-54)."""
+        p = _f32(p, self.device)
+        B, K = p.shape[:2]
+        loss = torch.empty(B, device=self.device, dtype=torch.float32)
+        grad = torch.empty(B, K, 3, device=self.device, dtype=torch.float32) if want_grad else None
+        idx = torch.empty(B, K, 5, device=self.device, dtype=torch.int32) if want_idx else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_repulsion(self.ctx, p.data_ptr(), B, K, loss.data_ptr(), self._ptr(grad),
+                                               self._ptr(idx), self._stream()))
+        out = (loss,) + ((grad,) if want_grad else ()) + ((idx,) if want_idx else ())
+        return out if len(out) > 1 else loss
+
+    def optimize_points(self, opt_points: torch.Tensor, c, rep_weight: float = 1.0, iterations: int = 1000,
+                        lr: float = 1e-3, loss_batch: Optional[int] = None, normalize: bool = True,
+                        state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
+                        return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None):
+        """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
+
+        Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
+        is given.  ``loss_batch`` is the reference batch size whose 1/B factor scales both losses
+        (default: the number of clouds passed in).  ``state=(m, v, t0)`` resumes / teacher-forces.
+        Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
+        is left to the caller.
+        """
+        planes = self._planes(c)
+        p = _f32(opt_points, self.device).clone()
+        B, K = p.shape[:2]
+        n_steps = int(iterations) + 1 if steps is None else int(steps)
+        t0 = 0
+        m = v = None
+        if state is not None:
+            m, v, t0 = _f32(state[0], self.device).clone(), _f32(state[1], self.device).clone(), int(state[2])
+        elif return_state:
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+        loss = torch.empty(B, 2, device=self.device, dtype=torch.float32) if return_loss else None
+        prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
+                           float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
+                                              self._ptr(m), self._ptr(v), self._ptr(loss), self._stream()))
+        out = (p,)
+        if return_state:
+            out += ((m, v, t0 + n_steps),)
+        if return_loss:
+            out += (loss,)
+        return out if len(out) > 1 else p
+
+    def normalize_batch_pc(self, points: torch.Tensor) -> torch.Tensor:
+        """normalize_batch_pc (opt_defense.py:76-83); returns a new tensor."""
+        p = _f32(points, self.device).clone()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_normalize_unit_sphere(self.ctx, p.data_ptr(), p.shape[0], p.shape[1],
+                                                           self._stream()))
+        return p

@@ -1,0 +1,133 @@
+/*
+ * ifd.h - C ABI of libifd.so: the MI355X (gfx950) implementation of IF-Defense's
+ * ConvONet-Opt restoration hot path.
+ *
+ * The reference (Wuziyi616/IF-Defense) has no plugin / FFI interface: the path
+ * sits behind Python call seams.  Each entry point below names the reference
+ * call it replaces (paths relative to the reference repo).  INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only, no torch / C++ types.
+ *   - every function returns an int status (IFD_OK == 0); nothing throws or
+ *     calls exit() across the ABI (the reference's OOM loops call exit(-1):
+ *     ConvONet/defense/repulsion_loss.py:30-32, SOR.py:57-59).
+ *   - all array arguments are DEVICE pointers owned by the caller unless the
+ *     name ends in _host.  float = IEEE binary32.  Arrays are dense, row-major.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *     are asynchronous with respect to the host; they never synchronise.
+ *   - a context is bound to one device and may be used from one thread at a
+ *     time; different contexts are independent (no hidden globals).
+ *
+ * Plane layout used on the device ("channel-last"):
+ *     planes[b][plane][row][col][ch],  plane in {0:xz, 1:xy, 2:yz}, row = u1 cell,
+ *     col = u0 cell, ch in [0,32)   ->  float[B][3][64][64][32]  (1.5 MiB / cloud)
+ * i.e. reference tensor c[plane][b, ch, row, col]
+ * (ConvONet/src/encoder/pointnet.py:79-80) permuted so that one bilinear tap is
+ * one contiguous 128-byte line.
+ */
+#ifndef IFD_H
+#define IFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFD_ABI_VERSION 1
+
+enum {
+    IFD_OK = 0,
+    IFD_ERR_ARG = -1,        /* bad argument (NULL, size out of the supported range) */
+    IFD_ERR_HIP = -2,        /* a HIP runtime call failed; see ifd_last_error() */
+    IFD_ERR_UNSUPPORTED = -3,/* valid in the reference but not built here (e.g. 'grid' planes) */
+    IFD_ERR_NOMEM = -4
+};
+
+/* Resolved hyper-parameters (ConvONet/configs/convonet_3plane_mn40.yaml + default.yaml).
+ * Only the shipped 3-plane configuration is supported; ifd_create validates it. */
+typedef struct ifd_config {
+    int32_t struct_size;      /* sizeof(ifd_config), for forward compatibility */
+    int32_t plane_resolution; /* 64   (yaml: model.encoder_kwargs.plane_resolution) */
+    int32_t c_dim;            /* 32   (yaml: model.c_dim) */
+    int32_t hidden_dim;       /* 32   (encoder hidden_dim == decoder hidden_size) */
+    int32_t n_blocks;         /* 5    (decoder.py:23, pointnet.py:33 defaults) */
+    int32_t unet_depth;       /* 4 */
+    int32_t unet_start_filts; /* 32 */
+    float   padding;          /* 0.1  (default.yaml data.padding) */
+} ifd_config;
+
+typedef struct ifd_ctx ifd_ctx;
+
+/* Number of floats ifd_create expects in `weights_host`, and the canonical
+ * order: the reference checkpoint's state_dict tensors, each in its native
+ * torch layout, concatenated in this order (names as in pretrain/convonet.pth):
+ *   decoder.fc_p.{weight[32,3],bias[32]}
+ *   decoder.fc_c.{0..4}.{weight[32,32],bias[32]}
+ *   decoder.blocks.{0..4}.{fc_0.weight[32,32],fc_0.bias,fc_1.weight[32,32],fc_1.bias}
+ *   decoder.fc_out.{weight[1,32],bias[1]}
+ *   encoder.fc_pos.{weight[64,3],bias[64]}
+ *   encoder.blocks.{0..4}.{fc_0.weight[32,64],fc_0.bias,fc_1.weight[32,32],fc_1.bias,shortcut.weight[32,64]}
+ *   encoder.fc_c.{weight[32,32],bias[32]}
+ *   encoder.unet.down_convs.{0..3}.{conv1.weight,conv1.bias,conv2.weight,conv2.bias}
+ *   encoder.unet.up_convs.{0..2}.{upconv.weight,upconv.bias,conv1.weight,conv1.bias,conv2.weight,conv2.bias}
+ *   encoder.unet.conv_final.{weight[32,32,1,1],bias[32]}
+ * Replaces: model.load_state_dict(torch.load(...)) (ConvONet/opt_defense.py:64-65). */
+size_t ifd_weight_count(void);
+
+int  ifd_abi_version(void);
+
+/* Replaces config.get_model + load_state_dict + get_generator
+ * (ConvONet/opt_defense.py:56-73).  `weights_host` is HOST memory. */
+ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_config* cfg, int device);
+void     ifd_destroy(ifd_ctx* ctx);
+const char* ifd_last_error(const ifd_ctx* ctx);   /* ctx may be NULL: error of the last failed ifd_create */
+
+/* ---- decoder / losses / optimiser: the 501-step hot loop --------------------- */
+
+/* generator.model.decode(p, c).logits (ConvONet/opt_defense.py:212 ->
+ * src/conv_onet/models/decoder.py:69-95).  p [B,K,3]; planes channel-last;
+ * logits [B,K]; dlogit_dp (optional, may be NULL) [B,K,3] = d(sum logits)/dp. */
+int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K,
+               float* logits, float* dlogit_dp, void* stream);
+
+/* repulsion_loss(p) (ConvONet/opt_defense.py:221 -> defense/repulsion_loss.py:18-54,
+ * defense/pn_utils.py:64-83).  loss [B] = mean over K*5 of (r-d)*exp(-(d/h)^2);
+ * grad (optional) [B,K,3] = d(sum_b loss_b)/dp;  knn_idx (optional) [B,K,5] int32,
+ * neighbours sorted by increasing distance. */
+int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K,
+                  float* loss, float* grad, int32_t* knn_idx, void* stream);
+
+typedef struct ifd_opt_params {
+    int32_t struct_size;  /* sizeof(ifd_opt_params) */
+    int32_t steps;        /* number of Adam steps = --iterations + 1 (opt_defense.py:210) */
+    int32_t t0;           /* steps already taken (0 for a fresh run); Adam bias correction uses t0+1.. */
+    int32_t loss_batch;   /* the reference's batch size B in the two torch.mean() (1/B factor, :215,:222) */
+    int32_t normalize;    /* !=0: finish with normalize_batch_pc (opt_defense.py:76-83,:238) */
+    float   lr;           /* --lr, 1e-3 */
+    float   rep_weight;   /* --rep_weight, 500 */
+    float   threshold;    /* cfg test.threshold, 0.2 */
+    float   rep_radius;   /* 0.07  (RepulsionLoss defaults, repulsion_loss.py:9-10) */
+    float   rep_h;        /* 0.03 */
+    float   rep_eps;      /* 1e-12 */
+} ifd_opt_params;
+
+/* optimize_points(opt_points, z, c, rep_weight, iterations) (ConvONet/opt_defense.py:182-239).
+ * p [B,K,3]: in = initial points, out = optimised (and normalised if requested).
+ * m, v (optional, both or neither) [B,K,3]: Adam moments, read when t0 > 0 and always
+ * written back - lets a caller resume or teacher-force single steps.
+ * loss (optional) [B,2]: {sum_k BCE_k, repulsion_loss_b} evaluated at the last step's
+ * pre-update points (what the reference prints at :229-236, before 1/B and weights).
+ * 6 <= K <= 1024. */
+int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
+                 const ifd_opt_params* prm, float* m, float* v, float* loss, void* stream);
+
+/* normalize_batch_pc (ConvONet/opt_defense.py:76-83) in place on p [B,K,3]. */
+int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IFD_H */

@@ -1,0 +1,104 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/ifd.h declares, and the host-side weight packing follows the documented canonical order."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ifd.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ifd_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import ifdefense_amd as I
+    if not os.path.exists(I.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ifd_build", os.path.join(ROOT, "if-defense_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    return I.load_library()
+
+
+def test_header_symbols_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), "libifd.so does not export %s declared in include/ifd.h" % n
+
+
+def test_binding_covers_header():
+    from ifdefense_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_exports_are_c_abi():
+    import ifdefense_amd as I
+    out = subprocess.run(["nm", "-D", "--defined-only", I.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "ifd_" in l.split()[-1][:4]}
+    assert set(declared_symbols()) <= exported
+
+
+def test_abi_version_and_weight_count(lib):
+    from ifdefense_amd import weights
+    assert lib.ifd_abi_version() == 1
+    n = sum(int(np.prod(s)) for _, s in weights.canonical_keys())
+    assert n == 16001 + 27232 + 1934976 == lib.ifd_weight_count()
+
+
+def test_pack_state_dict(np_weights):
+    from ifdefense_amd import weights
+    flat = weights.pack_state_dict(np_weights)
+    assert flat.dtype == np.float32 and flat.size == 1978209
+    np.testing.assert_array_equal(flat[:96], np_weights["decoder.fc_p.weight"].reshape(-1))
+    np.testing.assert_array_equal(flat[-32:], np_weights["encoder.unet.conv_final.bias"])
+    bad = dict(np_weights)
+    del bad["decoder.fc_out.bias"]
+    with pytest.raises(KeyError):
+        weights.pack_state_dict(bad)
+    bad = dict(np_weights)
+    bad["decoder.fc_p.weight"] = np.zeros((3, 32), np.float32)
+    with pytest.raises(ValueError):
+        weights.pack_state_dict(bad)
+
+
+def test_create_rejects_bad_arguments(lib):
+    """Argument validation happens before any HIP call, so it is testable without a GPU."""
+    from ifdefense_amd._lib import IfdConfig
+    cfg = IfdConfig(ctypes.sizeof(IfdConfig), 64, 32, 32, 5, 4, 32, 0.1)
+    w = np.zeros(10, np.float32)
+    assert not lib.ifd_create(w.ctypes.data, w.size, ctypes.byref(cfg), 0)
+    assert b"expected 1978209" in lib.ifd_last_error(None)
+    w = np.zeros(1978209, np.float32)
+    cfg.plane_resolution = 128
+    assert not lib.ifd_create(w.ctypes.data, w.size, ctypes.byref(cfg), 0)
+    assert b"only the shipped" in lib.ifd_last_error(None)
+    assert lib.ifd_optimize(None, None, None, 1, 1024, None, None, None, None, None) == -1
+
+
+def test_no_gpu_fails_loudly(np_weights):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ifdefense_amd as I
+    with pytest.raises(I.IfdError):
+        I.Restorer(I.weights.pack_state_dict(np_weights))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "if-defense_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
