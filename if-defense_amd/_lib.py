@@ -25,7 +25,7 @@ class IfdOptParams(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("steps", C.c_int32), ("t0", C.c_int32),
                 ("loss_batch", C.c_int32), ("normalize", C.c_int32), ("lr", C.c_float),
                 ("rep_weight", C.c_float), ("threshold", C.c_float), ("rep_radius", C.c_float),
-                ("rep_h", C.c_float), ("rep_eps", C.c_float)]
+                ("rep_h", C.c_float), ("rep_eps", C.c_float), ("knn_scan_every_step", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/ifd.h declares (tests check this)
@@ -41,6 +41,7 @@ SIGNATURES = {
                                 C.c_void_p]),
     "ifd_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ifd_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ifd_normalize_unit_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 

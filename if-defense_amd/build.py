@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libifd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
+         "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("IFD_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -80,6 +81,9 @@ struct ifd_ctx {
     std::vector<float> w;          // host copy, canonical order
     float* d_dec_img = nullptr;    // decoder parameter image (ifd_device.h layout)
     DecConst dc{};
+    unsigned long long* d_counters = nullptr;   // IFD_N_COUNTERS diagnostic counters of the last ifd_optimize
+    void* ws = nullptr;            // context-owned scratch (kNN lists, encoder activations), grown on demand
+    size_t ws_bytes = 0;
     std::string err;
 };
 
@@ -99,7 +103,7 @@ std::vector<float> build_dec_image(const float* w) {
     std::vector<float> img(DEC_FLOATS, 0.f);
     auto put_layer = [&](int L, size_t woff, size_t boff) {
         for (int o = 0; o < 32; ++o)
-            for (int k = 0; k < 32; ++k) img[DEC_OFF_W + L * W_LAYER + o * W_STRIDE + k] = w[woff + o * 32 + k];
+            for (int k = 0; k < 32; ++k) img[DEC_OFF_W + L * W_LAYER + o * W_STRIDE + wperm(k)] = w[woff + o * 32 + k];
         for (int o = 0; o < 32; ++o) img[DEC_OFF_BIAS + L * 32 + o] = w[boff + o];
     };
     for (int i = 0; i < 5; ++i) {
@@ -117,6 +121,22 @@ std::vector<float> build_dec_image(const float* w) {
 }
 
 bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > MAXK; }
+
+// Grow the context workspace.  Growing synchronises the device (hipFree), which only happens when a call
+// needs more scratch than any earlier call on this context.
+hipError_t ensure_ws(ifd_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return hipSuccess;
+    if (ctx->ws) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+        (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->ws, bytes);
+    if (e == hipSuccess) ctx->ws_bytes = bytes;
+    return e;
+}
 
 }  // namespace
 
@@ -155,10 +175,13 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         std::vector<float> img = build_dec_image(ctx->w.data());
         e = hipMemcpy(ctx->d_dec_img, img.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), IFD_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e != hipSuccess) {
         g_create_error = std::string("ifd_create: ") + hipGetErrorString(e);
         if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         delete ctx;
         return nullptr;
     }
@@ -168,6 +191,8 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
 void ifd_destroy(ifd_ctx* ctx) {
     if (!ctx) return;
     if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     delete ctx;
 }
 
@@ -199,11 +224,27 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
     OptArgs a;
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
+    a.knn_scan_every_step = prm->knn_scan_every_step;
+    { const char* d = getenv("IFD_SHARED_PLANES"); a.shared_planes = d ? atoi(d) : 0; }
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;
-    hipError_t e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, B, K, a, static_cast<hipStream_t>(stream));
+    hipError_t e = ensure_ws(ctx, knn_list_bytes(B));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
+    e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset", e);
+    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K,
+                        a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
+}
+
+int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
+    if (!ctx || !out_host || n < 1) return IFD_ERR_ARG;
+    unsigned long long tmp[IFD_N_COUNTERS] = {0};
+    hipError_t e = hipMemcpy(tmp, ctx->d_counters, sizeof(tmp), hipMemcpyDeviceToHost);   // synchronises
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_get_counters", e);
+    for (int i = 0; i < n; ++i) out_host[i] = i < IFD_N_COUNTERS ? tmp[i] : 0;
+    return IFD_OK;
 }
 
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream) {

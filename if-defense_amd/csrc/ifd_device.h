@@ -15,20 +15,22 @@ constexpr int PLANE_FLOATS = RES * RES * CH;        // one plane, channel-last
 constexpr int CLOUD_PLANE_FLOATS = 3 * PLANE_FLOATS; // 1.5 MiB / cloud
 
 // ---- decoder parameter image (identical in global memory and in LDS) -------------
-// W[15][32][33]: layer L = 3*i + j (j: 0 fc_c[i], 1 blocks[i].fc_0, 2 blocks[i].fc_1), row = out
-// channel, col = in channel, row stride padded to 33 floats so that both the row-gather (forward,
-// A[o][k]) and the column-gather (backward, A = W^T) are conflict-free ds_read_b32 patterns.
-constexpr int W_STRIDE = 33;
-constexpr int W_LAYER = 32 * W_STRIDE;               // 1056
+// W[15][32][34]: layer L = 3*i + j (j: 0 fc_c[i], 1 blocks[i].fc_0, 2 blocks[i].fc_1), row = out
+// channel o, column = wperm(in channel c), row stride 34 floats.  With the 16x16x4 MFMA operand mapping of
+// optimize.hip (lane = (n, q), A[m = n][k = q]) the forward A-operand gather W[16mt+n][16mt'+4q+r'] hits bank
+// (2n + q + const) mod 32 - conflict-free - and the transposed gather of the backward pass is 2-way at worst.
+constexpr int W_STRIDE = 34;
+constexpr int W_LAYER = 32 * W_STRIDE;               // 1088
+__host__ __device__ constexpr int wperm(int c) { return (c & 16) + 4 * (c & 3) + ((c >> 2) & 3); }
 constexpr int DEC_OFF_W = 0;
-constexpr int DEC_OFF_BIAS = 15 * W_LAYER;           // 15840: [15][32]
-constexpr int DEC_OFF_WP = DEC_OFF_BIAS + 15 * 32;   // 16320: [32][4] = {Wp[ch][0..2], bp[ch]}
-constexpr int DEC_OFF_WOUT = DEC_OFF_WP + 32 * 4;    // 16448: [32]
-constexpr int DEC_OFF_BOUT = DEC_OFF_WOUT + 32;      // 16480: [1] (+3 pad)
-constexpr int DEC_FLOATS = DEC_OFF_BOUT + 4;         // 16484 floats = 65,936 B
+constexpr int DEC_OFF_BIAS = 15 * W_LAYER;           // 16320: [15][32]
+constexpr int DEC_OFF_WP = DEC_OFF_BIAS + 15 * 32;   // [32][4] = {Wp[ch][0..2], bp[ch]}
+constexpr int DEC_OFF_WOUT = DEC_OFF_WP + 32 * 4;    // [32]
+constexpr int DEC_OFF_BOUT = DEC_OFF_WOUT + 32;      // [1] (+3 pad)
+constexpr int DEC_FLOATS = DEC_OFF_BOUT + 4;         // 16964 floats = 67,856 B
 
 constexpr int MAXK = 1024;           // points per cloud held in LDS
-constexpr int OPT_THREADS = 512;     // 8 waves: 2 per SIMD
+constexpr int OPT_THREADS = 512;     // 8 waves: 2 per SIMD (256 VGPRs each), two points per thread
 constexpr float FIX_SCALE = 1099511627776.0f;        // 2^40: fixed-point scale of the neighbour scatter
 constexpr float FIX_INV = 1.0f / 1099511627776.0f;
 

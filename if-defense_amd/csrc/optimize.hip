@@ -1,64 +1,95 @@
-// ConvONet-Opt hot loop for MI355X (gfx950): one workgroup owns one cloud for all Adam steps.
+// ConvONet-Opt hot loop for MI355X (gfx950): one workgroup (8 waves, 2 per SIMD, 256 VGPRs each) owns one
+// cloud for all Adam steps; one thread owns two points for the kNN / Adam phases, one wave owns a 16-point
+// tile at a time for the decoder phase.
 //
 //   per step (reference: ConvONet/opt_defense.py:210-228)
-//     phase A  decoder forward + input-gradient on 32-point tiles, one wave per tile:
-//              bilinear gather of the 3 channel-last planes (decoder.py:50-57), the 5-block
-//              ResNet MLP on v_mfma_f32_32x32x2_f32 (decoder.py:83-93, layers.py:39-48), BCE-to-
-//              threshold derivative (opt_defense.py:213-216), transposed MLP, re-gather for dc/du.
-//     phase B  brute-force 5-NN over the cloud's xyz held in LDS + repulsion loss gradient
-//              (defense/pn_utils.py:64-83, defense/repulsion_loss.py:43-54); neighbour terms are
-//              scattered with 64-bit fixed-point LDS atomics => order independent, bit reproducible.
+//     phase A  decoder forward + input-gradient on 16-point tiles:
+//              bilinear gather of the 3 channel-last planes (decoder.py:50-57), the 5-block ResNet MLP on
+//              v_mfma_f32_16x16x4_f32 (decoder.py:83-93, layers.py:39-48), BCE-to-threshold derivative
+//              (opt_defense.py:213-216), transposed MLP, dc/du from the taps still held in registers.
+//              All 24 tap loads of a tile are issued as one batch (one memory round trip per tile).
+//     phase B  exact 5-NN from certified neighbour lists (defense/pn_utils.py:64-83) + repulsion loss
+//              gradient (defense/repulsion_loss.py:43-54); neighbour terms are scattered with 64-bit
+//              fixed-point LDS atomics => order independent, bit reproducible.
 //     phase C  fused Adam update (torch.optim.Adam single-tensor form), moments in registers.
-//   Nothing but the plane taps is read from global memory inside the loop.
+//   Half of the waves run A then B, the other half B then A, so every SIMD always has MFMA work queued
+//   next to the VALU-only kNN work.  Nothing but the plane taps (and the L2-resident neighbour lists) is
+//   read from global memory inside the loop.
 //
-// MFMA operand mapping (32x32x2, f32): M = output channel, N = point of the tile, K = input
-// channel.  The accumulator layout (lane l: point l&31, register r: channel (r&3)+8(r>>2)+4(l>>5))
-// is exactly the B-operand layout of the next layer when MFMA step s consumes register s, so
-// activations never leave registers and never need a transpose; weights stream from LDS as the
-// A operand (one ds_read_b32 per MFMA, conflict-free thanks to the 33-float row stride).
+// MFMA operand mapping (16x16x4, f32): M = output channel, N = point of the tile, K = input channel.
+//   lane l = (n = l & 15, q = l >> 4).  A-operand: A[m = n][k = q];  B-operand: B[k = q][n];  C/D: lane
+//   (n, q), register r  <->  row 4q + r, column n.   With two M-tiles (mt = 0, 1) a lane therefore holds, for
+//   point n, the 8 channels 16 mt + 4 q + r  (register e = 4 mt + r).  MFMA step s = 4 mt' + r' consumes
+//   register s as its B operand (k-slot q <-> channel 16 mt' + 4 q + r'), i.e. the accumulator layout of
+//   one layer IS the B-operand layout of the next: activations never leave registers and are never
+//   transposed.  Weights stream from LDS as the A operand (one ds_read_b32 per MFMA, see ifd_device.h).
 #include "ifd_device.h"
 #include "ifd_internal.h"
 
 namespace ifd {
 
-__device__ __forceinline__ int chan(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// out[o][n] (+)= sum_k A[o][k] * in[k][n] with A = W (forward) or W^T (backward).
+struct Acc2 {
+    f32x4 t[2];     // M-tile 0 (channels 4q..4q+3) and M-tile 1 (channels 16+4q..)
+};
+
+// out[o][n] (+)= sum_c A[o][c] * in[c][n] with A = W (forward) or W^T (backward); 16 MFMAs, two
+// independent accumulator chains (the 40-cycle dependent latency of 16x16x4 is covered by alternating).
+// `lo` is the lane's offset into a layer (LaneOff below), made opaque once per tile so that the loop-invariant
+// LDS weight loads are not hoisted out of the tile loop by LICM (they would be spilled to scratch).
+struct LaneOff {
+    int fwd;    // n * S + q
+    int bwd;    // 4 q * S + wperm16(n)
+    int q4;     // 4 q
+};
+
 template <bool TRANSPOSED>
-__device__ __forceinline__ f32x16 dense32(const float* __restrict__ wl, int n, int hi, const f32x16& in,
-                                          f32x16 acc) {
-    const float* base = TRANSPOSED ? (wl + (4 * hi) * W_STRIDE + n) : (wl + n * W_STRIDE + 4 * hi);
+__device__ __forceinline__ Acc2 dense32(const float* __restrict__ wl, const LaneOff& lo, const f32x8& in, Acc2 acc) {
+    // forward : A = W[16 mt + n][16 mt' + 4 q + r']  at  (16 mt + n) * S + 16 mt' + 4 r' + q
+    // backward: A = W[16 mt' + 4 q + r'][16 mt + n]  at  (16 mt' + 4 q + r') * S + 16 mt + wperm16(n)
+    const float* base = wl + (TRANSPOSED ? lo.bwd : lo.fwd);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int o = (s & 3) + 8 * (s >> 2);
-        const float a = base[TRANSPOSED ? o * W_STRIDE : o];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[s], acc, 0, 0, 0);
+    for (int s = 0; s < 8; ++s) {
+        const int mtp = s >> 2, rp = s & 3;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + 16 * mt) : (16 * mt * W_STRIDE + 16 * mtp + 4 * rp);
+            acc.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(base[off], in[s], acc.t[mt], 0, 0, 0);
+        }
     }
-    __builtin_amdgcn_sched_barrier(0);       // do not hoist the next layer's weight loads over this one
+    // Keep the next layer's weight loads behind this layer.  (An explicit one-layer-ahead register prefetch
+    // of the A operands was measured slower: +32 VGPRs of live fragments push spills into the tile loop.)
+    __builtin_amdgcn_sched_barrier(0);
     return acc;
 }
 
-__device__ __forceinline__ f32x16 load_bias(const float* __restrict__ W, int layer, int hi) {
-    f32x16 b;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(W + DEC_OFF_BIAS + layer * 32 + 8 * g + 4 * hi);
-        b[4 * g + 0] = t.x; b[4 * g + 1] = t.y; b[4 * g + 2] = t.z; b[4 * g + 3] = t.w;
-    }
+__device__ __forceinline__ Acc2 load_bias(const float* __restrict__ W, int layer, const LaneOff& lo) {
+    Acc2 b;
+    b.t[0] = *reinterpret_cast<const f32x4*>(W + DEC_OFF_BIAS + layer * 32 + lo.q4);
+    b.t[1] = *reinterpret_cast<const f32x4*>(W + DEC_OFF_BIAS + layer * 32 + 16 + lo.q4);
     return b;
 }
 
-__device__ __forceinline__ uint32_t mask_pos(const f32x16& v) {
+__device__ __forceinline__ f32x8 flat(const Acc2& a) {
+    f32x8 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o[r] = a.t[0][r]; o[4 + r] = a.t[1][r]; }
+    return o;
+}
+
+__device__ __forceinline__ uint32_t mask_pos(const f32x8& v) {
     uint32_t m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m |= (v[r] > 0.f ? 1u : 0u) << r;
+    for (int r = 0; r < 8; ++r) m |= (v[r] > 0.f ? 1u : 0u) << r;
     return m;
 }
 
-__device__ __forceinline__ f32x16 relu16(const f32x16& v) {
-    f32x16 o;
+__device__ __forceinline__ f32x8 relu8(const f32x8& v) {
+    f32x8 o;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = fmaxf(v[r], 0.f);
+    for (int r = 0; r < 8; ++r) o[r] = fmaxf(v[r], 0.f);
     return o;
 }
 
@@ -75,14 +106,16 @@ __device__ __forceinline__ void pixel_coord(float xa, const DecConst& dc, float&
 
 enum { MODE_OPT = 0, MODE_SUM = 1 };
 
-// One 32-point tile on one wave.  Every lane pair (l, l^32) works on point l&31 and holds 16 of its
-// 32 channels.  Returns logit, the BCE term and d(loss)/dx (valid on every lane after the pair reduce).
+// One 16-point tile on one wave.  The 4 lanes (n, q = 0..3) share point n and hold 8 of its 32 channels each.
+// Returns logit, the BCE term and d(loss)/dx (valid on every lane after the quad reduce).
 template <int MODE, bool WANT_GRAD>
 __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const float* __restrict__ planes,
                                              float x0, float x1, float x2, int lane, const DecConst dc,
                                              float thr, float inv_lb, float& logit_out, float& bce_out,
                                              float (&dx)[3]) {
-    const int n = lane & 31, hi = lane >> 5;
+    const int n = lane & 15, q = lane >> 4;
+    LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
+    asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
     float pix[3], live[3];
     pixel_coord(x0, dc, pix[0], live[0]);
     pixel_coord(x1, dc, pix[1], live[1]);
@@ -98,71 +131,88 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
     }
     constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
 
-    // ---- forward: c = sum over planes of the bilinear sample -------------------------------
-    f32x16 c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    // ---- gather: all 12 taps x 8 channels of this lane in ONE batch of 24 loads, kept for the backward ---
+    f32x4 tap[3][4][2];        // [plane][nw, ne, sw, se][M-tile]  = 96 VGPRs
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
         const int a0 = AX0[P], a1 = AX1[P];
-        const float* q = planes + ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * hi;
+        const float* qp = planes + ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            tap[P][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+            tap[P][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+            tap[P][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+            tap[P][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+        }
+    }
+    // ---- forward: c = sum over planes of the bilinear sample -------------------------------------
+    f32x8 c;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) c[r] = 0.f;
+#pragma unroll
+    for (int P = 0; P < 3; ++P) {
+        const int a0 = AX0[P], a1 = AX1[P];
         const float wnw = w0[a0] * w0[a1], wne = w1[a0] * w0[a1], wsw = w0[a0] * w1[a1], wse = w1[a0] * w1[a1];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 tnw = *reinterpret_cast<const f32x4*>(q + 8 * g);
-            const f32x4 tne = *reinterpret_cast<const f32x4*>(q + CH + 8 * g);
-            const f32x4 tsw = *reinterpret_cast<const f32x4*>(q + RES * CH + 8 * g);
-            const f32x4 tse = *reinterpret_cast<const f32x4*>(q + RES * CH + CH + 8 * g);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s = tnw[j] * wnw;
-                s = fmaf(tne[j], wne, s);
-                s = fmaf(tsw[j], wsw, s);
-                s = fmaf(tse[j], wse, s);
-                c[4 * g + j] += s;
+                float s = tap[P][0][mt][j] * wnw;
+                s = fmaf(tap[P][1][mt][j], wne, s);
+                s = fmaf(tap[P][2][mt][j], wsw, s);
+                s = fmaf(tap[P][3][mt][j], wse, s);
+                c[4 * mt + j] += s;
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep at most one plane's 16 tap loads in flight
     }
 
-    // ---- forward MLP ------------------------------------------------------------------------
-    f32x16 net;
+    // ---- forward MLP ------------------------------------------------------------------------------
+    Acc2 net;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (8 * g + 4 * hi + j) * 4);
-            net[4 * g + j] = fmaf(wp.z, x2, fmaf(wp.y, x1, fmaf(wp.x, x0, wp.w)));
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
+            net.t[mt][j] = fmaf(wp.z, x2, fmaf(wp.y, x1, fmaf(wp.x, x0, wp.w)));
         }
     uint32_t mask_a[NBLK], mask_h[NBLK];
+    const float* Wd = W + DEC_OFF_W;
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) {
-        const float* Wl = W + DEC_OFF_W + 3 * i * W_LAYER;
-        f32x16 a = net + load_bias(W, 3 * i, hi);
-        a = dense32<false>(Wl, n, hi, c, a);                          // a_i = n_i + fc_c[i](c)
-        mask_a[i] = mask_pos(a);
-        f32x16 h = load_bias(W, 3 * i + 1, hi);
-        h = dense32<false>(Wl + W_LAYER, n, hi, relu16(a), h);        // fc_0(relu(a))
-        mask_h[i] = mask_pos(h);
-        f32x16 o = a + load_bias(W, 3 * i + 2, hi);
-        net = dense32<false>(Wl + 2 * W_LAYER, n, hi, relu16(h), o);  // a + fc_1(relu(h))
+        const float* Wl = Wd + 3 * i * W_LAYER;
+        Acc2 a = load_bias(W, 3 * i, lo);
+        a.t[0] += net.t[0];
+        a.t[1] += net.t[1];
+        a = dense32<false>(Wl, lo, c, a);                                       // a_i = n_i + fc_c[i](c)
+        const f32x8 af = flat(a);
+        mask_a[i] = mask_pos(af);
+        const Acc2 h = dense32<false>(Wl + W_LAYER, lo, relu8(af), load_bias(W, 3 * i + 1, lo));   // fc_0(relu(a))
+        const f32x8 hf = flat(h);
+        mask_h[i] = mask_pos(hf);
+        Acc2 o = load_bias(W, 3 * i + 2, lo);
+        o.t[0] += a.t[0];
+        o.t[1] += a.t[1];
+        net = dense32<false>(Wl + 2 * W_LAYER, lo, relu8(hf), o);               // a + fc_1(relu(h))
     }
-    const uint32_t mask_n = mask_pos(net);
-    float wout[16];
+    const f32x8 nf = flat(net);
+    const uint32_t mask_n = mask_pos(nf);
+    f32x8 wout;
+    {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + lo.q4);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 8 * g + 4 * hi);
-        wout[4 * g + 0] = t.x; wout[4 * g + 1] = t.y; wout[4 * g + 2] = t.z; wout[4 * g + 3] = t.w;
+        for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
     }
     float part = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part = fmaf(wout[r], fmaxf(net[r], 0.f), part);
-    const float logit = part + __shfl_xor(part, 32) + W[DEC_OFF_BOUT];
+    for (int r = 0; r < 8; ++r) part = fmaf(wout[r], fmaxf(nf[r], 0.f), part);
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    const float logit = part + W[DEC_OFF_BOUT];
     logit_out = logit;
     bce_out = 0.f;
     if (!WANT_GRAD) return;
 
-    // ---- backward (parameters frozen: only the path to the input) --------------------------------
+    // ---- backward (parameters frozen: only the path to the input) ----------------------------------
     float dl;
     if (MODE == MODE_OPT) {
         const float e = expf(-fabsf(logit));
@@ -172,65 +222,60 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
     } else {
         dl = 1.f;
     }
-    f32x16 dn, zero;
+    f32x8 dn;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        zero[r] = 0.f;
-        dn[r] = ((mask_n >> r) & 1u) ? dl * wout[r] : 0.f;
-    }
-    f32x16 dcc = zero;
+    for (int r = 0; r < 8; ++r) dn[r] = ((mask_n >> r) & 1u) ? dl * wout[r] : 0.f;
+    Acc2 zero;
+    zero.t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    zero.t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Acc2 dcc = zero;
 #pragma unroll
     for (int i = NBLK - 1; i >= 0; --i) {
-        const float* Wl = W + DEC_OFF_W + 3 * i * W_LAYER;
-        f32x16 dh = dense32<true>(Wl + 2 * W_LAYER, n, hi, dn, zero);
+        const float* Wl = Wd + 3 * i * W_LAYER;
+        f32x8 dh = flat(dense32<true>(Wl + 2 * W_LAYER, lo, dn, zero));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh[r] = ((mask_h[i] >> r) & 1u) ? dh[r] : 0.f;
-        const f32x16 t = dense32<true>(Wl + W_LAYER, n, hi, dh, zero);
+        for (int r = 0; r < 8; ++r) dh[r] = ((mask_h[i] >> r) & 1u) ? dh[r] : 0.f;
+        const f32x8 t = flat(dense32<true>(Wl + W_LAYER, lo, dh, zero));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dn[r] += ((mask_a[i] >> r) & 1u) ? t[r] : 0.f;   // delta a_i
-        dcc = dense32<true>(Wl, n, hi, dn, dcc);                                       // += Wc^T delta a_i
+        for (int r = 0; r < 8; ++r) dn[r] += ((mask_a[i] >> r) & 1u) ? t[r] : 0.f;   // delta a_i
+        dcc = dense32<true>(Wl, lo, dn, dcc);                                          // += Wc^T delta a_i
     }
+    const f32x8 dcf = flat(dcc);
     float g[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (8 * gi + 4 * hi + j) * 4);
-            const float d = dn[4 * gi + j];
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
+            const float d = dn[4 * mt + j];
             g[0] = fmaf(wp.x, d, g[0]); g[1] = fmaf(wp.y, d, g[1]); g[2] = fmaf(wp.z, d, g[2]);
         }
     // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid)
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
         const int a0 = AX0[P], a1 = AX1[P];
-        int off = ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * hi;
-        // opaque to the optimiser: otherwise these loads are CSE'd with the forward gather and all
-        // 192 tap registers stay live (and spill) across the whole MLP.  The re-read is L1/L2 traffic.
-        asm volatile("" : "+v"(off));
-        const float* q = planes + off;
         float dnw = 0.f, dne = 0.f, dsw = 0.f, dse = 0.f;
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            const f32x4 tnw = *reinterpret_cast<const f32x4*>(q + 8 * gi);
-            const f32x4 tne = *reinterpret_cast<const f32x4*>(q + CH + 8 * gi);
-            const f32x4 tsw = *reinterpret_cast<const f32x4*>(q + RES * CH + 8 * gi);
-            const f32x4 tse = *reinterpret_cast<const f32x4*>(q + RES * CH + CH + 8 * gi);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float d = dcc[4 * gi + j];
-                dnw = fmaf(tnw[j], d, dnw); dne = fmaf(tne[j], d, dne);
-                dsw = fmaf(tsw[j], d, dsw); dse = fmaf(tse[j], d, dse);
+                const float d = dcf[4 * mt + j];
+                dnw = fmaf(tap[P][0][mt][j], d, dnw); dne = fmaf(tap[P][1][mt][j], d, dne);
+                dsw = fmaf(tap[P][2][mt][j], d, dsw); dse = fmaf(tap[P][3][mt][j], d, dse);
             }
-        }
         const float gix = (dne - dnw) * w0[a1] + (dse - dsw) * w1[a1];
         const float giy = (dsw - dnw) * w0[a0] + (dse - dne) * w1[a0];
         const float sc = (0.5f * (float)(RES - 1)) * 2.f;
         g[a0] += live[a0] * ((gix * sc) / dc.sdiv);
         g[a1] += live[a1] * ((giy * sc) / dc.sdiv);
-        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) dx[a] = g[a] + __shfl_xor(g[a], 32);
+    for (int a = 0; a < 3; ++a) {
+        float v = g[a];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        dx[a] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,28 +291,32 @@ __device__ __forceinline__ void top5_init(Top5& t) {
     t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
 }
 
-__device__ __forceinline__ void top5_insert(Top5& t, float d, int j) {
-    if (d < t.d4) {
-        const bool c3 = d < t.d3, c2 = d < t.d2, c1 = d < t.d1, c0 = d < t.d0;
-        t.d4 = c3 ? t.d3 : d;                 t.i4 = c3 ? t.i3 : j;
-        t.d3 = c3 ? (c2 ? t.d2 : d) : t.d3;   t.i3 = c3 ? (c2 ? t.i2 : j) : t.i3;
-        t.d2 = c2 ? (c1 ? t.d1 : d) : t.d2;   t.i2 = c2 ? (c1 ? t.i1 : j) : t.i2;
-        t.d1 = c1 ? (c0 ? t.d0 : d) : t.d1;   t.i1 = c1 ? (c0 ? t.i0 : j) : t.i1;
-        t.d0 = c0 ? d : t.d0;                 t.i0 = c0 ? j : t.i0;
-    }
+// Branch-free sorted insertion (bubble the new key down with selects).  NOTE: the obvious nested-ternary
+// form is turned into exec-mask control flow by hipcc (4x the code, I-cache thrash) - keep this shape.
+__device__ __forceinline__ void top5_insert_nb(Top5& t, float d, int j) {
+    bool c; float lo; int li;
+    c = d < t.d0; lo = c ? d : t.d0; li = c ? j : t.i0; d = c ? t.d0 : d; j = c ? t.i0 : j; t.d0 = lo; t.i0 = li;
+    c = d < t.d1; lo = c ? d : t.d1; li = c ? j : t.i1; d = c ? t.d1 : d; j = c ? t.i1 : j; t.d1 = lo; t.i1 = li;
+    c = d < t.d2; lo = c ? d : t.d2; li = c ? j : t.i2; d = c ? t.d2 : d; j = c ? t.i2 : j; t.d2 = lo; t.i2 = li;
+    c = d < t.d3; lo = c ? d : t.d3; li = c ? j : t.i3; d = c ? t.d3 : d; j = c ? t.i3 : j; t.d3 = lo; t.i3 = li;
+    c = d < t.d4; t.d4 = c ? d : t.d4; t.i4 = c ? j : t.i4;
 }
 
-// Brute-force scan of all K points (broadcast LDS reads) for the two points owned by this thread.
-__device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, int pa, int pb, Top5& ta,
-                                          Top5& tb) {
+__device__ __forceinline__ void top5_insert(Top5& t, float d, int j) {
+    if (d < t.d4) top5_insert_nb(t, d, j);      // rare after the first few dozen candidates
+}
+
+// Exact brute-force scan of all K points (broadcast LDS reads) for the two points of this thread
+// (self excluded by index).
+__device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, int pa, int pb, Top5& ta, Top5& tb) {
     const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
     top5_init(ta);
     top5_init(tb);
 #pragma unroll 4
     for (int j = 0; j < K; ++j) {
         const f32x4 xj = X[j];
-        float ax = xj.x - xa.x, ay = xj.y - xa.y, az = xj.z - xa.z;
-        float bx = xj.x - xb.x, by = xj.y - xb.y, bz = xj.z - xb.z;
+        const float ax = xj.x - xa.x, ay = xj.y - xa.y, az = xj.z - xa.z;
+        const float bx = xj.x - xb.x, by = xj.y - xb.y, bz = xj.z - xb.z;
         float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
         float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
         da = (j == pa) ? INFINITY : da;
@@ -275,6 +324,133 @@ __device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, in
         top5_insert(ta, da, j);
         top5_insert(tb, db, j);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Certified neighbour lists: exact 5-NN at O(LIST_M) per point per step.
+//
+//   build (rare, all waves of the cloud in the same step):  for each point i store every j with
+//       |x_j - x_i| < rho_i, rho_i^2 = alpha2_i * (an upper bound of i's squared 5-NN distance); alpha2_i
+//       adapts so that the ball holds <= LIST_M points.  x0_i = x_i at build time.
+//   step:  the 5 nearest list members are the true 5-NN iff  r5 < rho_i - |x_i - x0_i| - Dmax, with
+//       Dmax = max_j |x_j - x0_j|  (a point outside the list was >= rho_i away at build time).
+//       soft margin violated -> request a synchronous rebuild for the NEXT step (nobody stalls alone);
+//       certificate violated -> this wave runs the exact brute-force scan for this step.
+//   Either way every step uses the exact 5-NN set; ties follow ascending j like the scan.
+// ---------------------------------------------------------------------------------------------
+#ifndef IFD_LIST_M
+#define IFD_LIST_M 32
+#endif
+constexpr int LIST_M = IFD_LIST_M;       // entries per point (uint16), lists live in global memory (L2)
+constexpr int STAGE_M = 16;              // LDS staging entries per point during a rebuild (32 B)
+
+// 5 nearest of points ia / ib among their lists (global memory, entries [0,cnt) valid); the two independent
+// insertion chains are interleaved for ILP.  cnt < 0 (no list) leaves the result at +inf.
+__device__ __forceinline__ void list_top5_2(const f32x4* __restrict__ X, const uint16_t* La, const uint16_t* Lb,
+                                            int cnt_a, int cnt_b, int ia, int ib, Top5& ta, Top5& tb) {
+    const f32x4 xa = X[ia], xb = X[ib];
+    top5_init(ta);
+    top5_init(tb);
+#pragma unroll
+    for (int c = 0; c < LIST_M / 8; ++c) {
+        const u32x4 wa = reinterpret_cast<const u32x4*>(La)[c], wb = reinterpret_cast<const u32x4*>(Lb)[c];
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = c * 8 + e8;
+            const unsigned int pka = wa[e8 >> 1], pkb = wb[e8 >> 1];
+            const int ja = (e8 & 1) ? (int)(pka >> 16) : (int)(pka & 0xffffu);
+            const int jb = (e8 & 1) ? (int)(pkb >> 16) : (int)(pkb & 0xffffu);
+            const bool va = e < cnt_a, vb = e < cnt_b;
+            const f32x4 pa_ = X[va ? ja : ia], pb_ = X[vb ? jb : ib];
+            const float ax = pa_.x - xa.x, ay = pa_.y - xa.y, az = pa_.z - xa.z;
+            const float bx = pb_.x - xb.x, by = pb_.y - xb.y, bz = pb_.z - xb.z;
+            float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
+            float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
+            da = va ? da : INFINITY;
+            db = vb ? db : INFINITY;
+            top5_insert_nb(ta, da, ja);
+            top5_insert_nb(tb, db, jb);
+        }
+    }
+}
+
+// Append candidate j to a point's list: entries are staged in the lane's private 32-byte LDS slot and
+// flushed to the global list as whole 32-byte chunks (2-byte global stores from 64 divergent lanes cost
+// ~270 us per rebuild; chunked they are noise).  n counts all candidates, stored or not.
+__device__ __forceinline__ void list_append(uint16_t* __restrict__ stage, uint16_t* __restrict__ lst, int& n, int j) {
+    if (n < LIST_M) {
+        stage[n & (STAGE_M - 1)] = (uint16_t)j;
+        if ((n & (STAGE_M - 1)) == STAGE_M - 1) {
+            const u32x4* sp = reinterpret_cast<const u32x4*>(stage);
+            u32x4* gp = reinterpret_cast<u32x4*>(lst + (n & ~(STAGE_M - 1)));
+            gp[0] = sp[0];
+            gp[1] = sp[1];
+        }
+    }
+    ++n;
+}
+__device__ __forceinline__ void list_flush_tail(const uint16_t* __restrict__ stage, uint16_t* __restrict__ lst, int n) {
+    if (n < LIST_M && (n & (STAGE_M - 1)) != 0) {
+        const u32x4* sp = reinterpret_cast<const u32x4*>(stage);
+        u32x4* gp = reinterpret_cast<u32x4*>(lst + (n & ~(STAGE_M - 1)));
+        gp[0] = sp[0];
+        gp[1] = sp[1];
+    }
+}
+
+// (Re)build the lists of the two points owned by each lane of this wave.  r5sq_* are upper bounds of the
+// squared 5-NN distances (INFINITY = unknown -> exact brute-force scan first, results left in ta/tb).  al_*
+// (alpha^2) adapt: shrink in proportion to the overshoot and retry when a ball holds > LIST_M points, grow
+// slowly when it is sparsely filled.  cnt_* = -1 on return means "ball too crowded, no list".  Returns #passes.
+struct KnnPt {
+    int cnt;        // valid list entries, -1 = no list
+    float rho;      // the list holds every point that was within rho of x0 at build time
+    float al;       // alpha^2: rho^2 = al * (upper bound of the squared 5-NN distance)
+    f32x4 x0;       // position at build time
+};
+
+__device__ __forceinline__ int knn_rebuild(const f32x4* __restrict__ X, int K, int pa, int pb,
+                                           uint16_t* __restrict__ La, uint16_t* __restrict__ Lb,
+                                           uint16_t* __restrict__ Sa, uint16_t* __restrict__ Sb, float r5sq_a,
+                                           float r5sq_b, Top5& ta, Top5& tb, KnnPt& ka, KnnPt& kb) {
+    if (__any(!(r5sq_a < INFINITY) || !(r5sq_b < INFINITY))) {
+        knn_scan2(X, K, pa, pb, ta, tb);
+        r5sq_a = ta.d4;
+        r5sq_b = tb.d4;
+    }
+    const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
+    int na = 0, nb = 0, passes = 0;
+    float tha = 0.f, thb = 0.f;
+#pragma unroll 1
+    for (int tries = 0; tries < 4; ++tries) {
+        tha = r5sq_a * ka.al;
+        thb = r5sq_b * kb.al;
+        na = nb = 0;
+        ++passes;
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) {
+            const f32x4 xj = X[j];
+            const float ax = xj.x - xa.x, ay = xj.y - xa.y, az = xj.z - xa.z;
+            const float bx = xj.x - xb.x, by = xj.y - xb.y, bz = xj.z - xb.z;
+            const float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
+            const float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
+            if (da < tha && j != pa) list_append(Sa, La, na, j);
+            if (db < thb && j != pb) list_append(Sb, Lb, nb, j);
+        }
+        const bool ova = na > LIST_M, ovb = nb > LIST_M;
+        if (!__any(ova || ovb)) break;
+        ka.al = ova ? fmaxf(ka.al * ((float)LIST_M / (float)na) * 0.8f, 1.08f) : ka.al;
+        kb.al = ovb ? fmaxf(kb.al * ((float)LIST_M / (float)nb) * 0.8f, 1.08f) : kb.al;
+    }
+    list_flush_tail(Sa, La, na);
+    list_flush_tail(Sb, Lb, nb);
+    ka.cnt = na <= LIST_M ? na : -1;
+    kb.cnt = nb <= LIST_M ? nb : -1;
+    ka.rho = sqrtf(tha);
+    kb.rho = sqrtf(thb);
+    ka.al = na < (LIST_M * 2) / 5 ? fminf(ka.al * 1.15f, 25.f) : ka.al;
+    kb.al = nb < (LIST_M * 2) / 5 ? fminf(kb.al * 1.15f, 25.f) : kb.al;
+    return passes;
 }
 
 struct RepConst {
@@ -320,6 +496,8 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
 // ---------------------------------------------------------------------------------------------
 // block helpers
 // ---------------------------------------------------------------------------------------------
+constexpr int NWAVES = OPT_THREADS / 64;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -330,7 +508,7 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-// deterministic block reductions over OPT_THREADS threads; `scratch` holds >= 8 floats
+// deterministic block reductions; `scratch` holds >= NWAVES floats
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_sum(v);
@@ -380,41 +558,42 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
-    float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out, int K, OptArgs A) {
+    float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out, uint16_t* knn_lists,
+    unsigned long long* __restrict__ counters, int K, OptArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W = smem;
-    f32x4* X = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);
-    f32x4* G = X + MAXK;
-    long long* F = reinterpret_cast<long long*>(G + MAXK);
-    float* scratch = reinterpret_cast<float*>(F + 3 * MAXK);   // 64 floats
+    float* W = smem;                                                 // decoder parameter image
+    f32x4* X = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // current points
+    f32x4* G = X + MAXK;                                             // occupancy gradient (+ BCE term in .w)
+    long long* F = reinterpret_cast<long long*>(G + MAXK);           // fixed-point neighbour-gradient scatter
+    uint16_t* L = reinterpret_cast<uint16_t*>(F + 3 * MAXK);         // list staging [MAXK][STAGE_M] (rebuilds)
+    float* scratch = reinterpret_cast<float*>(L + MAXK * STAGE_M);   // 96 floats
 
     const int cloud = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
+    const float* pl = planes + (A.shared_planes ? (size_t)0 : (size_t)cloud * CLOUD_PLANE_FLOATS);
     float* pc = p + (size_t)cloud * K * 3;
-    const int pa = tid, pb = tid + OPT_THREADS;
-    const int ntiles = (K + 31) >> 5;
+    const int pa = tid, pb = tid + OPT_THREADS;                      // the two points this thread owns
+    const int ntiles = (K + 15) >> 4;
 
     load_dec_image(W, dec_img);
     float mm[6], vv[6];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int pt = q ? pb : pa;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) mm[3 * q + a] = vv[3 * q + a] = 0.f;
         if (pt < K) {
             X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
+            if (A.t0 > 0 && m_io != nullptr) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const bool have = A.t0 > 0 && m_io != nullptr;
-                mm[3 * q + a] = have ? m_io[((size_t)cloud * K + pt) * 3 + a] : 0.f;
-                vv[3 * q + a] = have ? v_io[((size_t)cloud * K + pt) * 3 + a] : 0.f;
+                for (int a = 0; a < 3; ++a) {
+                    mm[3 * q + a] = m_io[((size_t)cloud * K + pt) * 3 + a];
+                    vv[3 * q + a] = v_io[((size_t)cloud * K + pt) * 3 + a];
+                }
             }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) mm[3 * q + a] = vv[3 * q + a] = 0.f;
         }
     }
     for (int i = tid; i < MAXK * 3; i += OPT_THREADS) F[i] = 0;
-    __syncthreads();
 
     const DecConst dc = A.dc;
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
@@ -423,28 +602,84 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
     const bool use_rep = A.rep_weight > 0.f;
     double b1t = pow(0.9, (double)A.t0), b2t = pow(0.999, (double)A.t0);
     float rep_loss_a = 0.f, rep_loss_b = 0.f;
+    // certified neighbour lists of the two owned points
+    uint16_t* La = knn_lists + ((size_t)cloud * MAXK + pa) * LIST_M;        // global (L2-resident)
+    uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + pb) * LIST_M;
+    uint16_t* Sa = L + pa * STAGE_M;                                         // LDS staging slots (rebuilds)
+    uint16_t* Sb = L + pb * STAGE_M;
+    KnnPt ka = {-1, 0.f, 0.16f * LIST_M, f32x4{0.f, 0.f, 0.f, 0.f}};         // al: ~80 % fill on a flat patch
+    KnnPt kb = ka;
+    float* dmaxbuf = scratch + 32;                                   // [2][NWAVES] per-wave max |x - x0| (next step)
+    float* movebuf = scratch + 64;                                   // [2][NWAVES] per-wave max single-step move
+    volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
+    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0;
+    if (tid < 2) rebuild_flag[tid] = 0;
+    if (tid < 2 * NWAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
+    __syncthreads();
 
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
         float gca[3] = {0.f, 0.f, 0.f}, gcb[3] = {0.f, 0.f, 0.f};
-        // waves 0-3 (one per SIMD) run decoder then kNN, waves 4-7 the other way round, so the MFMA
-        // pipe of each SIMD always has a decoder wave while its partner does the VALU-only kNN.
+        // waves 0-3 (one per SIMD) run decoder then kNN, waves 4-7 the other way round.
 #pragma unroll 1
         for (int phase = 0; phase < 2; ++phase) {
-            const bool do_dec = (phase == 0) == (wave < 4);
+            const bool do_dec = (phase == 0) == (wave < NWAVES / 2);
             if (do_dec) {
 #pragma unroll 1
-                for (int tile = wave; tile < ntiles; tile += OPT_THREADS / 64) {
-                    const int pt = min(tile * 32 + (lane & 31), K - 1);
-                    const f32x4 x = X[pt];
+                for (int tile = wave; tile < ntiles; tile += NWAVES) {
+                    const int tp = min(tile * 16 + (lane & 15), K - 1);
+                    const f32x4 x = X[tp];
                     float logit, bce, dx[3];
                     decoder_tile<MODE_OPT, true>(W, pl, x.x, x.y, x.z, lane, dc, A.threshold, inv_lb, logit,
                                                  bce, dx);
-                    if (lane < 32 && tile * 32 + lane < K) G[pt] = f32x4{dx[0], dx[1], dx[2], bce};
+                    if (lane < 16 && tile * 16 + lane < K) G[tp] = f32x4{dx[0], dx[1], dx[2], bce};
                 }
             } else if (use_rep) {
                 Top5 ta, tb;
-                knn_scan2(X, K, pa, pb, ta, tb);
+                top5_init(ta);
+                top5_init(tb);
+                const int ia = min(pa, K - 1), ib = min(pb, K - 1);
+                if (A.knn_scan_every_step) {
+                    knn_scan2(X, K, pa, pb, ta, tb);
+                } else {
+                    const bool force = step == 0 || rebuild_flag[step & 1] != 0;      // block-uniform
+                    float dmax = 0.f, mv = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWAVES; ++w) {
+                        dmax = fmaxf(dmax, dmaxbuf[(step & 1) * NWAVES + w]);
+                        mv = fmaxf(mv, movebuf[(step & 1) * NWAVES + w]);
+                    }
+                    // the certificate must survive one more step: r5 grows <= 2 mv, both displacements <= mv
+                    const float soft_slack = 6.f * mv;
+#pragma unroll 1
+                    for (int attempt = 0;; ++attempt) {
+                        list_top5_2(X, La, Lb, ka.cnt, kb.cnt, ia, ib, ta, tb);
+                        if (!force || attempt == 1) break;
+                        ++n_rebuild;
+                        n_pass += knn_rebuild(X, K, pa, pb, La, Lb, Sa, Sb, ta.d4, tb.d4, ta, tb, ka, kb);
+                        ka.x0 = X[ia];
+                        kb.x0 = X[ib];
+                        dmax = 0.f;
+                    }
+                    const f32x4 xa = X[ia], xb = X[ib];
+                    const float da0 = sqrtf((xa.x - ka.x0.x) * (xa.x - ka.x0.x) + (xa.y - ka.x0.y) * (xa.y - ka.x0.y) +
+                                            (xa.z - ka.x0.z) * (xa.z - ka.x0.z));
+                    const float db0 = sqrtf((xb.x - kb.x0.x) * (xb.x - kb.x0.x) + (xb.y - kb.x0.y) * (xb.y - kb.x0.y) +
+                                            (xb.z - kb.x0.z) * (xb.z - kb.x0.z));
+                    // every point outside the list is farther than this bound (build radius minus both moves)
+                    const float bnd_a = (ka.rho - da0 - dmax) * 0.99999f - 1e-7f;
+                    const float bnd_b = (kb.rho - db0 - dmax) * 0.99999f - 1e-7f;
+                    const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
+                    const bool hard = (pa >= K || (ka.cnt >= 0 && r5a < bnd_a)) && (pb >= K || (kb.cnt >= 0 && r5b < bnd_b));
+                    const bool soft_a = pa >= K || ka.cnt < 0 || r5a < bnd_a - soft_slack;
+                    const bool soft_b = pb >= K || kb.cnt < 0 || r5b < bnd_b - soft_slack;
+                    if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
+                        ++n_brute;
+                        knn_scan2(X, K, pa, pb, ta, tb);
+                    }
+                    // crowded balls (cnt < 0) can only be served by the scan; they do not ask for rebuilds
+                    if (__any(!(soft_a && soft_b)) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
+                }
                 if (pa < K) rep_point(X, F, pa, ta, rc, rep_loss_a, gca, true);
                 if (pb < K) rep_point(X, F, pb, tb, rc, rep_loss_b, gcb, true);
             }
@@ -455,12 +690,11 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
             float rep = (pa < K ? rep_loss_a : 0.f) + (pb < K ? rep_loss_b : 0.f);
             occ = wave_sum(occ);
             rep = wave_sum(rep);
-            float (*red)[OPT_THREADS / 64] = reinterpret_cast<float (*)[OPT_THREADS / 64]>(scratch);
-            if (lane == 0) { red[0][wave] = occ; red[1][wave] = rep; }
+            if (lane == 0) { scratch[wave] = occ; scratch[NWAVES + wave] = rep; }
             __syncthreads();
             if (tid == 0) {
                 float so = 0.f, sr = 0.f;
-                for (int w = 0; w < OPT_THREADS / 64; ++w) { so += red[0][w]; sr += red[1][w]; }
+                for (int w = 0; w < NWAVES; ++w) { so += scratch[w]; sr += scratch[NWAVES + w]; }
                 loss_out[2 * cloud + 0] = so;
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
@@ -471,14 +705,16 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
         b2t *= 0.999;
         const float step_size = (float)((double)A.lr / (1.0 - b1t));
         const float bc2 = (float)sqrt(1.0 - b2t);
+        float dmax2 = 0.f, mv2 = 0.f;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pt = q ? pb : pa;
             if (pt < K) {
                 const f32x4 go = G[pt];
-                f32x4 x = X[pt];
+                const f32x4 x = X[pt];
                 const float gocc[3] = {go.x, go.y, go.z};
                 float xs[3] = {x.x, x.y, x.z};
+                float msq = 0.f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const float gn = __ll2float_rn(F[3 * pt + a]) * FIX_INV;
@@ -490,14 +726,33 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
                     mr = mr + (g - mr) * (1.f - 0.9f);
                     vr = vr * 0.999f + (1.f - 0.999f) * g * g;
                     const float denom = sqrtf(vr) / bc2 + 1e-8f;
-                    xs[a] = xs[a] - step_size * (mr / denom);
+                    const float upd = step_size * (mr / denom);
+                    xs[a] = xs[a] - upd;
+                    msq = fmaf(upd, upd, msq);
                 }
+                const f32x4 x0 = q ? kb.x0 : ka.x0;
+                const float dsq = (xs[0] - x0.x) * (xs[0] - x0.x) + (xs[1] - x0.y) * (xs[1] - x0.y) +
+                                  (xs[2] - x0.z) * (xs[2] - x0.z);
+                dmax2 = fmaxf(dmax2, dsq);
+                mv2 = fmaxf(mv2, msq);
                 X[pt] = f32x4{xs[0], xs[1], xs[2], 0.f};
             }
         }
+        dmax2 = wave_max(dmax2);
+        mv2 = wave_max(mv2);
+        if (lane == 0) {
+            dmaxbuf[((step + 1) & 1) * NWAVES + wave] = sqrtf(dmax2) * 1.00001f + 1e-7f;
+            movebuf[((step + 1) & 1) * NWAVES + wave] = sqrtf(mv2);
+        }
+        if (tid == 0) rebuild_flag[step & 1] = 0;      // consumed by every wave before the mid-step barrier
         __syncthreads();
     }
 
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(counters + 0, (unsigned long long)n_rebuild);   // wave-level list rebuilds
+        atomicAdd(counters + 1, (unsigned long long)n_brute);     // wave-level certificate failures (exact scans)
+        atomicAdd(counters + 2, (unsigned long long)n_pass);      // wave-level candidate-collection passes
+    }
     if (A.normalize) normalize_in_lds(X, K, scratch);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -531,19 +786,19 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void decode_kernel(const float* __r
     __syncthreads();
     const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
     const float* pc = p + (size_t)cloud * K * 3;
-    const int ntiles = (K + 31) >> 5;
-    for (int tile = wave; tile < ntiles; tile += OPT_THREADS / 64) {
-        const int pt = min(tile * 32 + (lane & 31), K - 1);
-        const float x0 = pc[3 * pt], x1 = pc[3 * pt + 1], x2 = pc[3 * pt + 2];
+    const int ntiles = (K + 15) >> 4;
+    for (int tile = wave; tile < ntiles; tile += NWAVES) {
+        const int tp = min(tile * 16 + (lane & 15), K - 1);
+        const float x0 = pc[3 * tp], x1 = pc[3 * tp + 1], x2 = pc[3 * tp + 2];
         float logit, bce, dx[3] = {0.f, 0.f, 0.f};
         if (dlogit_dp != nullptr)
             decoder_tile<MODE_SUM, true>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
         else
             decoder_tile<MODE_SUM, false>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
-        if (lane < 32 && tile * 32 + lane < K) {
-            logits[(size_t)cloud * K + pt] = logit;
+        if (lane < 16 && tile * 16 + lane < K) {
+            logits[(size_t)cloud * K + tp] = logit;
             if (dlogit_dp != nullptr) {
-                float* o = dlogit_dp + ((size_t)cloud * K + pt) * 3;
+                float* o = dlogit_dp + ((size_t)cloud * K + tp) * 3;
                 o[0] = dx[0]; o[1] = dx[1]; o[2] = dx[2];
             }
         }
@@ -614,10 +869,13 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + MAXK * 3 * 8 + 256;     // 123,536 B
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + MAXK * 3 * 8 + MAXK * STAGE_M * 2 + 96 * 4;   // 158,352 B
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;
 constexpr size_t NRM_LDS = MAXK * 16 + 64;
+static_assert(OPT_LDS <= 160 * 1024, "LDS budget");
+
+size_t knn_list_bytes(int B) { return (size_t)B * MAXK * LIST_M * sizeof(uint16_t); }
 
 hipError_t configure_optimize_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel),
@@ -629,9 +887,10 @@ hipError_t configure_optimize_kernels() {
 }
 
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
-                           float* loss, int B, int K, const OptArgs& a, hipStream_t s) {
+                           float* loss, uint16_t* knn_lists, unsigned long long* counters, int B, int K,
+                           const OptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(optimize_kernel, dim3(B), dim3(OPT_THREADS), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                       K, a);
+                       knn_lists, counters, K, a);
     return hipGetLastError();
 }
 

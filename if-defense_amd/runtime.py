@@ -112,7 +112,8 @@ class Restorer:
     def optimize_points(self, opt_points: torch.Tensor, c, rep_weight: float = 1.0, iterations: int = 1000,
                         lr: float = 1e-3, loss_batch: Optional[int] = None, normalize: bool = True,
                         state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
-                        return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None):
+                        return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
+                        knn_scan_every_step: bool = False):
         """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
@@ -133,7 +134,8 @@ class Restorer:
             m, v = torch.zeros_like(p), torch.zeros_like(p)
         loss = torch.empty(B, 2, device=self.device, dtype=torch.float32) if return_loss else None
         prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
-                           float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12)
+                           float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12,
+                           int(bool(knn_scan_every_step)))
         with torch.cuda.device(self.device):
             self._check(self.lib.ifd_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
                                               self._ptr(m), self._ptr(v), self._ptr(loss), self._stream()))
@@ -143,6 +145,12 @@ class Restorer:
         if return_loss:
             out += (loss,)
         return out if len(out) > 1 else p
+
+    def counters(self) -> Dict[str, int]:
+        """Diagnostic counters of the last optimize_points call (synchronises)."""
+        buf = (C.c_uint64 * 8)()
+        self._check(self.lib.ifd_get_counters(self.ctx, buf, 8))
+        return {"knn_rebuilds": int(buf[0]), "knn_brute_scans": int(buf[1]), "knn_passes": int(buf[2])}
 
     def normalize_batch_pc(self, points: torch.Tensor) -> torch.Tensor:
         """normalize_batch_pc (opt_defense.py:76-83); returns a new tensor."""

@@ -112,6 +112,8 @@ typedef struct ifd_opt_params {
     float   rep_radius;   /* 0.07  (RepulsionLoss defaults, repulsion_loss.py:9-10) */
     float   rep_h;        /* 0.03 */
     float   rep_eps;      /* 1e-12 */
+    int32_t knn_scan_every_step; /* validation only: !=0 disables the certified neighbour lists and runs the
+                                    exact brute-force 5-NN scan at every step (same results, slower) */
 } ifd_opt_params;
 
 /* optimize_points(opt_points, z, c, rep_weight, iterations) (ConvONet/opt_defense.py:182-239).
@@ -123,6 +125,12 @@ typedef struct ifd_opt_params {
  * 6 <= K <= 1024. */
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
                  const ifd_opt_params* prm, float* m, float* v, float* loss, void* stream);
+
+/* Diagnostics (no reference counterpart): counters of the most recent ifd_optimize on this context, copied
+ * to HOST memory; synchronises the device.  [0] wave-level neighbour-list rebuilds, [1] wave-level certificate
+ * failures served by the exact brute-force scan, [2] wave-level candidate-collection passes.  n <= IFD_N_COUNTERS. */
+#define IFD_N_COUNTERS 8
+int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
 
 /* normalize_batch_pc (ConvONet/opt_defense.py:76-83) in place on p [B,K,3]. */
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream);

@@ -38,3 +38,5 @@ for _ in range(a.reps):
           % (B, a.steps, ms, cps, ms * 1e3 / a.steps / max(1, (B + 255) // 256),
              cps * 2 * 15488 * 2 * 1024 * a.steps / 1e12, cps * 2 * 15488 * 2 * 1024 * a.steps / 157.3e12 * 100))
 assert torch.isfinite(out).all()
+c = r.counters()
+print('counters', c, '-> rebuilds per wave per run: %.1f' % (c['knn_rebuilds'] / (B * 8)))

@@ -170,6 +170,26 @@ def test_p4_determinism_and_sharding_invariance(restorer, golden, oracle_weights
     assert torch.equal(torch.cat([lo, hi]), a)                   # shard-and-concatenate bitwise
 
 
+def test_certified_neighbour_lists_equal_exact_scan(restorer, golden, oracle_weights):
+    """The O(32)-per-point certified list path must reproduce the brute-force 5-NN scan bit for bit."""
+    from oracle import convonet_oracle as O
+    import ifdefense_amd as I
+    proc = [golden["proc_pad"][b, :golden["proc_len"][b]] for b in range(4)]
+    sel = torch.from_numpy(np.stack([proc[b][golden["sel_idx"][b]] for b in range(4)]))
+    planes4 = I.planes_to_channel_last(O.encode_inputs(oracle_weights, sel)).cuda()
+    init = torch.from_numpy(golden["init_points"]).cuda()
+    for K in (1024, 333, 40):
+        a = restorer.optimize_points(init[:, :K], planes4, rep_weight=500.0, iterations=150, normalize=False)
+        c = restorer.counters()
+        b = restorer.optimize_points(init[:, :K], planes4, rep_weight=500.0, iterations=150, normalize=False,
+                                     knn_scan_every_step=True)
+        assert torch.equal(a, b), (K, float((a - b).abs().max()))
+        ev = c["knn_rebuilds"] / (4 * 8)
+        print("K=%d: %.1f synchronous list rebuilds per cloud over 151 steps, %d certificate failures" %
+              (K, ev, c["knn_brute_scans"]))
+        assert ev < 151 and c["knn_brute_scans"] <= 8 * 4 * 3, c     # lists must actually be reused across steps
+
+
 def test_rep_weight_zero_and_small_k(restorer, golden, planes2, oracle_weights):
     from oracle import convonet_oracle as O
     init = torch.from_numpy(golden["init_points"][:2, :100]).clone()
