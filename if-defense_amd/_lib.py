@@ -28,6 +28,11 @@ class IfdOptParams(C.Structure):
                 ("rep_h", C.c_float), ("rep_eps", C.c_float), ("knn_scan_every_step", C.c_int32)]
 
 
+class IfdPrepParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("n_sel", C.c_int32), ("n_opt", C.c_int32), ("padding_scale", C.c_float),
+                ("init_sigma", C.c_float), ("seed", C.c_uint64), ("cloud_index_base", C.c_int64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/ifd.h declares (tests check this)
 SIGNATURES = {
     "ifd_abi_version": (C.c_int, []),
@@ -35,6 +40,15 @@ SIGNATURES = {
     "ifd_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(IfdConfig), C.c_int]),
     "ifd_destroy": (None, [C.c_void_p]),
     "ifd_last_error": (C.c_char_p, [C.c_void_p]),
+    "ifd_sor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                          C.c_void_p]),
+    "ifd_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdPrepParams),
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]),
+    "ifd_encode_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "ifd_unet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ifd_encode_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ifd_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
     "ifd_repulsion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

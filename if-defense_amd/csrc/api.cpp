@@ -80,6 +80,12 @@ struct ifd_ctx {
     ifd_config cfg{};
     std::vector<float> w;          // host copy, canonical order
     float* d_dec_img = nullptr;    // decoder parameter image (ifd_device.h layout)
+    float* d_w = nullptr;          // the whole canonical weight vector on the device (encoder kernels index it)
+    EncPointOffsets eo{};
+    float* d_unet = nullptr;       // re-packed U-Net weights ([tap][Cin][Cout])
+    UNetWeights uw{};
+    void* ws_enc = nullptr;        // encoder scratch (pre-U-Net planes + U-Net activations), grown on demand
+    size_t ws_enc_bytes = 0;
     DecConst dc{};
     unsigned long long* d_counters = nullptr;   // IFD_N_COUNTERS diagnostic counters of the last ifd_optimize
     void* ws = nullptr;            // context-owned scratch (kNN lists, encoder activations), grown on demand
@@ -124,18 +130,67 @@ bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > MAXK; }
 
 // Grow the context workspace.  Growing synchronises the device (hipFree), which only happens when a call
 // needs more scratch than any earlier call on this context.
-hipError_t ensure_ws(ifd_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->ws_bytes) return hipSuccess;
-    if (ctx->ws) {
+hipError_t ensure_buf(void** buf, size_t* have, size_t bytes) {
+    if (bytes <= *have) return hipSuccess;
+    if (*buf) {
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) return e;
-        (void)hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
+        (void)hipFree(*buf);
+        *buf = nullptr;
+        *have = 0;
     }
-    hipError_t e = hipMalloc(&ctx->ws, bytes);
-    if (e == hipSuccess) ctx->ws_bytes = bytes;
+    hipError_t e = hipMalloc(buf, bytes);
+    if (e == hipSuccess) *have = bytes;
     return e;
+}
+hipError_t ensure_ws(ifd_ctx* ctx, size_t bytes) { return ensure_buf(&ctx->ws, &ctx->ws_bytes, bytes); }
+
+// Re-pack the U-Net convolutions to [tap][Cin][Cout] (Conv2d weight [Cout][Cin][kh][kw]; ConvTranspose2d weight
+// [Cin][Cout][kh][kw]) and record where each tensor starts.
+struct UNetPack {
+    std::vector<float> data;
+    size_t down_w[4][2], down_b[4][2], up_t_w[3], up_t_b[3], up_w[3][2], up_b[3][2], fin_w, fin_b;
+};
+UNetPack pack_unet(const float* w) {
+    const WeightMap& m = wmap();
+    UNetPack P;
+    auto conv = [&](size_t src, int co, int ci, int k) {
+        size_t at = P.data.size();
+        P.data.resize(at + (size_t)k * k * ci * co);
+        for (int o = 0; o < co; ++o)
+            for (int i = 0; i < ci; ++i)
+                for (int t = 0; t < k * k; ++t) P.data[at + ((size_t)t * ci + i) * co + o] = w[src + ((size_t)o * ci + i) * k * k + t];
+        return at;
+    };
+    auto convt = [&](size_t src, int ci, int co) {
+        size_t at = P.data.size();
+        P.data.resize(at + (size_t)4 * ci * co);
+        for (int i = 0; i < ci; ++i)
+            for (int o = 0; o < co; ++o)
+                for (int t = 0; t < 4; ++t) P.data[at + ((size_t)t * ci + i) * co + o] = w[src + ((size_t)i * co + o) * 4 + t];
+        return at;
+    };
+    auto vec = [&](size_t src, int n) {
+        size_t at = P.data.size();
+        P.data.insert(P.data.end(), w + src, w + src + n);
+        return at;
+    };
+    const int ch[4] = {32, 64, 128, 256};
+    int cin = 32;
+    for (int i = 0; i < 4; ++i) {
+        P.down_w[i][0] = conv(m.down_w[i][0], ch[i], cin, 3); P.down_b[i][0] = vec(m.down_b[i][0], ch[i]);
+        P.down_w[i][1] = conv(m.down_w[i][1], ch[i], ch[i], 3); P.down_b[i][1] = vec(m.down_b[i][1], ch[i]);
+        cin = ch[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        const int co = cin / 2;
+        P.up_t_w[i] = convt(m.up_t_w[i], cin, co); P.up_t_b[i] = vec(m.up_t_b[i], co);
+        P.up_w[i][0] = conv(m.up_w[i][0], co, 2 * co, 3); P.up_b[i][0] = vec(m.up_b[i][0], co);
+        P.up_w[i][1] = conv(m.up_w[i][1], co, co, 3); P.up_b[i][1] = vec(m.up_b[i][1], co);
+        cin = co;
+    }
+    P.fin_w = conv(m.fin_w, 32, 32, 1); P.fin_b = vec(m.fin_b, 32);
+    return P;
 }
 
 }  // namespace
@@ -177,11 +232,41 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), IFD_N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_w), n_weights * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_w, ctx->w.data(), n_weights * sizeof(float), hipMemcpyHostToDevice);
+    {
+        const WeightMap& m = wmap();
+        EncPointOffsets& o = ctx->eo;
+        o.pos_w = (int)m.enc_pos_w; o.pos_b = (int)m.enc_pos_b; o.fcc_w = (int)m.enc_fcc_w; o.fcc_b = (int)m.enc_fcc_b;
+        for (int i = 0; i < 5; ++i) {
+            o.fc0_w[i] = (int)m.enc_fc0_w[i]; o.fc0_b[i] = (int)m.enc_fc0_b[i];
+            o.fc1_w[i] = (int)m.enc_fc1_w[i]; o.fc1_b[i] = (int)m.enc_fc1_b[i];
+            o.sc_w[i] = (int)m.enc_sc_w[i];
+        }
+    }
+    if (e == hipSuccess) {
+        UNetPack P = pack_unet(ctx->w.data());
+        e = hipMalloc(reinterpret_cast<void**>(&ctx->d_unet), P.data.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_unet, P.data.data(), P.data.size() * sizeof(float), hipMemcpyHostToDevice);
+        const float* d = ctx->d_unet;
+        UNetWeights& u = ctx->uw;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j) { u.down_w[i][j] = d + P.down_w[i][j]; u.down_b[i][j] = d + P.down_b[i][j]; }
+        for (int i = 0; i < 3; ++i) {
+            u.up_t_w[i] = d + P.up_t_w[i]; u.up_t_b[i] = d + P.up_t_b[i];
+            for (int j = 0; j < 2; ++j) { u.up_w[i][j] = d + P.up_w[i][j]; u.up_b[i][j] = d + P.up_b[i][j]; }
+        }
+        u.fin_w = d + P.fin_w; u.fin_b = d + P.fin_b;
+    }
+    if (e == hipSuccess) e = configure_encoder_kernels();
+    if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e != hipSuccess) {
         g_create_error = std::string("ifd_create: ") + hipGetErrorString(e);
         if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_w) (void)hipFree(ctx->d_w);
+        if (ctx->d_unet) (void)hipFree(ctx->d_unet);
         delete ctx;
         return nullptr;
     }
@@ -193,7 +278,73 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_w) (void)hipFree(ctx->d_w);
+    if (ctx->d_unet) (void)hipFree(ctx->d_unet);
+    if (ctx->ws_enc) (void)hipFree(ctx->ws_enc);
     delete ctx;
+}
+
+int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uint8_t* keep_mask, double* value,
+            void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!pc || !keep_mask || B < 1 || K < 2 || K > 2048 || k < 1 || k > 7 || k >= K)
+        return fail(ctx, IFD_ERR_ARG, "ifd_sor: bad argument (2 <= K <= 2048, 1 <= k <= 7)");
+    hipError_t e = launch_sor(pc, B, K, k, (double)alpha, keep_mask, value, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_sor launch", e);
+}
+
+int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, int K, const ifd_prep_params* prm,
+                const int32_t* sel_idx, const int32_t* init_idx, const float* noise, float* sel, int32_t* t_per_cloud,
+                float* init_points, int32_t* n_kept, float* proc, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!pc || !prm || prm->struct_size != (int32_t)sizeof(ifd_prep_params) || !sel || !t_per_cloud || !init_points ||
+        B < 1 || K < 1 || K > 2048 || prm->n_sel < 1 || prm->n_sel > 1024 || prm->n_opt < 1)
+        return fail(ctx, IFD_ERR_ARG, "ifd_prepare: bad argument (K <= 2048, n_sel <= 1024)");
+    PrepArgs a;
+    a.cloud_base = (int)prm->cloud_index_base; a.n_sel = prm->n_sel; a.n_opt = prm->n_opt;
+    a.padding_scale = prm->padding_scale; a.init_sigma = prm->init_sigma;
+    a.seed_lo = (uint32_t)(prm->seed & 0xffffffffu); a.seed_hi = (uint32_t)(prm->seed >> 32);
+    hipError_t e = launch_prepare(pc, keep_mask, B, K, a, sel_idx, init_idx, noise, sel, t_per_cloud, init_points, n_kept,
+                                  proc, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_prepare launch", e);
+}
+
+int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* planes_pre,
+                      float* c_points, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!sel || !planes_pre || B < 1 || Tmax < 1 || Tmax > 1024)
+        return fail(ctx, IFD_ERR_ARG, "ifd_encode_points: bad argument (1 <= Tmax <= 1024)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(planes_pre, 0, (size_t)B * CLOUD_PLANE_FLOATS * sizeof(float), s);
+    if (e == hipSuccess)
+        e = launch_encode_points(ctx->d_w, ctx->eo, sel, t_per_cloud, B, Tmax, planes_pre, c_points, ctx->dc, s);
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_encode_points", e);
+}
+
+int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!planes_pre || !planes || B < 1) return fail(ctx, IFD_ERR_ARG, "ifd_unet: bad argument");
+    hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, unet_workspace_floats(3 * B) * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_unet workspace", e);
+    e = launch_unet(ctx->uw, planes_pre, planes, static_cast<float*>(ctx->ws_enc), 3 * B, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_unet launch", e);
+}
+
+int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* planes,
+                      void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (!sel || !planes || B < 1 || Tmax < 1 || Tmax > 1024)
+        return fail(ctx, IFD_ERR_ARG, "ifd_encode_planes: bad argument (1 <= Tmax <= 1024)");
+    // scratch = [pre-U-Net planes | U-Net activations]
+    const size_t pre_floats = (size_t)B * CLOUD_PLANE_FLOATS;
+    hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, (pre_floats + unet_workspace_floats(3 * B)) * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_encode_planes workspace", e);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* pre = static_cast<float*>(ctx->ws_enc);
+    e = hipMemsetAsync(pre, 0, pre_floats * sizeof(float), s);
+    if (e == hipSuccess) e = launch_encode_points(ctx->d_w, ctx->eo, sel, t_per_cloud, B, Tmax, pre, nullptr, ctx->dc, s);
+    if (e == hipSuccess) e = launch_unet(ctx->uw, pre, planes, pre + pre_floats, 3 * B, s);
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_encode_planes", e);
 }
 
 int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,

@@ -13,6 +13,36 @@ struct OptArgs {
     DecConst dc;
 };
 
+// offsets (floats) of the point-net tensors inside the canonical weight vector (include/ifd.h order)
+struct EncPointOffsets {
+    int pos_w, pos_b, fc0_w[5], fc0_b[5], fc1_w[5], fc1_b[5], sc_w[5], fcc_w, fcc_b;
+};
+
+hipError_t configure_encoder_kernels();
+hipError_t launch_encode_points(const float* w, const EncPointOffsets& eo, const float* sel, const int* t_per_cloud,
+                                int B, int Tmax, float* planes, float* c_out, DecConst dc, hipStream_t s);
+
+// device pointers to the re-packed ([tap][Cin][Cout]) U-Net weights
+struct UNetWeights {
+    const float *down_w[4][2], *down_b[4][2];
+    const float *up_t_w[3], *up_t_b[3], *up_w[3][2], *up_b[3][2];
+    const float *fin_w, *fin_b;
+};
+size_t unet_workspace_floats(int n_img);
+hipError_t launch_unet(const UNetWeights& W, const float* x, float* out, float* ws, int n_img, hipStream_t s);
+
+struct PrepArgs {
+    int cloud_base;            // global index of cloud 0 of this call (RNG counter)
+    int n_sel, n_opt;          // encoder subset size (600), optimised points per cloud (1024)
+    float padding_scale, init_sigma;
+    uint32_t seed_lo, seed_hi;
+};
+hipError_t configure_prep_kernels();
+hipError_t launch_sor(const float* pc, int B, int K, int k_nn, double alpha, uint8_t* keep, double* value, hipStream_t s);
+hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, const PrepArgs& a, const int32_t* sel_idx,
+                          const int32_t* init_idx, const float* noise, float* sel, int32_t* t_per_cloud, float* init,
+                          int32_t* n_kept, float* proc_out, hipStream_t s);
+
 hipError_t configure_optimize_kernels();
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
                            uint16_t* knn_lists, unsigned long long* counters, int B, int K, const OptArgs& a,

@@ -1,0 +1,251 @@
+// Pre-processing in front of the encoder / optimiser, one workgroup per cloud:
+//   sor_kernel      SORDefense.outlier_removal (ConvONet/defense/SOR.py:22-49): float64 expanded-form squared
+//                   distances, the 2 nearest non-first neighbours' mean, keep value <= mean + alpha * std.
+//   prepare_kernel  preprocess_pc (ConvONet/opt_defense.py:114-146: centre, scale by the largest bbox extent,
+//                   * padding_scale, random 600-subset without replacement) and init_points (:149-179: 1024
+//                   indices with replacement, + N(0, sigma^2) noise, clamp to +-0.5*padding_scale).
+// The reference draws from unseeded global RNGs; here every draw is a pure function of
+// (seed, global cloud index, draw index) via Philox-4x32-10, so results do not depend on how clouds are
+// batched or sharded over GPUs.  For parity tests the draws can be passed in explicitly.
+#include "ifd_device.h"
+#include "ifd_internal.h"
+
+namespace ifd {
+
+constexpr int PREP_THREADS = 1024;
+constexpr int PREP_MAXK = 2048;          // largest input cloud (points) these kernels accept
+
+// ---- Philox-4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
+
+// deterministic block reductions (fixed order), doubles
+__device__ __forceinline__ double block_sum_d(double v, double* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += scratch[w];
+    return s;
+}
+__device__ __forceinline__ float block_minmax_f(float v, bool is_max, float* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, u) : fminf(v, u);
+    }
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float s = scratch[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s = is_max ? fmaxf(s, scratch[w]) : fminf(s, scratch[w]);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PREP_THREADS) void sor_kernel(const float* __restrict__ pc, int K, int k_nn, double alpha,
+                                                            uint8_t* __restrict__ keep, double* __restrict__ value_out) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    double* X = dsm;                      // [K][3]
+    double* XX = X + 3 * PREP_MAXK;       // [K]   |x|^2
+    double* VAL = XX + PREP_MAXK;         // [K]
+    double* scratch = VAL + PREP_MAXK;    // [16]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = pc + (size_t)b * K * 3;
+    for (int i = tid; i < K; i += PREP_THREADS) {
+        const double x = (double)p[3 * i], y = (double)p[3 * i + 1], z = (double)p[3 * i + 2];
+        X[3 * i] = x; X[3 * i + 1] = y; X[3 * i + 2] = z;
+        XX[i] = x * x + y * y + z * z;
+    }
+    __syncthreads();
+    double vsum = 0.0;
+    for (int i = tid; i < K; i += PREP_THREADS) {
+        const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2], xx = XX[i];
+        // k_nn + 1 smallest of dist[i][j] = xx_j + (-2 x_i.x_j) + xx_i over ALL j (self included, as the reference);
+        // k_nn <= 7
+        double best[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) best[q] = INFINITY;
+        for (int j = 0; j < K; ++j) {
+            const double inner = -2.0 * (x * X[3 * j] + y * X[3 * j + 1] + z * X[3 * j + 2]);
+            double d = (XX[j] + inner) + xx;
+            if (d < best[7]) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool c = d < best[q];
+                    const double lo = c ? d : best[q];
+                    d = c ? best[q] : d;
+                    best[q] = lo;
+                }
+            }
+        }
+        double v = 0.0;                    // mean of neighbours 1..k_nn (the smallest, "self", is dropped)
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v += q <= k_nn ? best[q] : 0.0;
+        v /= (double)k_nn;
+        VAL[i] = v;
+        vsum += v;
+        if (value_out) value_out[(size_t)b * K + i] = v;
+    }
+    const double mean = block_sum_d(vsum, scratch) / (double)K;
+    double sq = 0.0;
+    for (int i = tid; i < K; i += PREP_THREADS) { const double d = VAL[i] - mean; sq += d * d; }
+    const double var = block_sum_d(sq, scratch) / (double)(K - 1);       // torch.std: unbiased
+    const double thr = mean + alpha * sqrt(var);
+    for (int i = tid; i < K; i += PREP_THREADS) keep[(size_t)b * K + i] = VAL[i] <= thr ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __restrict__ pc, const uint8_t* __restrict__ keep,
+                                                                int K, PrepArgs A, const int32_t* __restrict__ sel_idx,
+                                                                const int32_t* __restrict__ init_idx,
+                                                                const float* __restrict__ noise, float* __restrict__ sel,
+                                                                int32_t* __restrict__ t_per_cloud, float* __restrict__ init,
+                                                                int32_t* __restrict__ n_kept, float* __restrict__ proc_out) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* P = fsm;                                                   // [PREP_MAXK][3] kept points, then processed
+    uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * PREP_MAXK);   // [PREP_MAXK] random keys for the subset
+    int* POS = reinterpret_cast<int*>(KEY + PREP_MAXK);               // [PREP_MAXK] compaction prefix
+    float* scratch = reinterpret_cast<float*>(POS + PREP_MAXK);       // [64]
+    int* s_n = reinterpret_cast<int*>(scratch + 62);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t gcloud = (uint32_t)(A.cloud_base + b);
+    const float* p = pc + (size_t)b * K * 3;
+    const uint8_t* km = keep ? keep + (size_t)b * K : nullptr;
+
+    // ---- stable compaction of the kept points (boolean-mask indexing keeps the original order) --------
+    if (tid == 0) {
+        int n = 0;
+        for (int i = 0; i < K; ++i) { POS[i] = n; n += (!km || km[i]) ? 1 : 0; }
+        *s_n = n;
+    }
+    __syncthreads();
+    const int n = *s_n;
+    __syncthreads();
+    for (int i = tid; i < K; i += PREP_THREADS)
+        if (!km || km[i]) { P[3 * POS[i]] = p[3 * i]; P[3 * POS[i] + 1] = p[3 * i + 1]; P[3 * POS[i] + 2] = p[3 * i + 2]; }
+    __syncthreads();
+    if (tid == 0 && n_kept) n_kept[b] = n;
+
+    // ---- centre, scale (opt_defense.py:122-127) --------------------------------------------------------
+    double* dscr = reinterpret_cast<double*>(scratch);
+    float cen[3], ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += PREP_THREADS) s += (double)P[3 * i + a];
+        cen[a] = (float)(block_sum_d(s, dscr) / (double)n);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mx = -INFINITY, mn = INFINITY;
+        for (int i = tid; i < n; i += PREP_THREADS) { const float v = P[3 * i + a] - cen[a]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
+        mx = block_minmax_f(mx, true, scratch);
+        mn = block_minmax_f(mn, false, scratch);
+        ext = fmaxf(ext, mx - mn);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PREP_THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) P[3 * i + a] = (P[3 * i + a] - cen[a]) / ext * A.padding_scale;
+    }
+    __syncthreads();
+    if (proc_out)
+        for (int i = tid; i < n * 3; i += PREP_THREADS) proc_out[(size_t)b * K * 3 + i] = P[i];
+
+    // ---- encoder subset: T points without replacement, in random order (np.random.choice(replace=False)) -
+    const int T = A.n_sel;
+    float* so = sel + (size_t)b * T * 3;
+    int tcount;
+    if (n > T) {
+        tcount = T;
+        if (sel_idx) {
+            for (int t = tid; t < T; t += PREP_THREADS) {
+                const int j = sel_idx[(size_t)b * T + t];
+                so[3 * t] = P[3 * j]; so[3 * t + 1] = P[3 * j + 1]; so[3 * t + 2] = P[3 * j + 2];
+            }
+        } else {
+            for (int i = tid; i < n; i += PREP_THREADS) KEY[i] = philox(gcloud, (uint32_t)i, 1u, 0u, A.seed_lo, A.seed_hi).x;
+            __syncthreads();
+            for (int i = tid; i < n; i += PREP_THREADS) {
+                const uint32_t ki = KEY[i];
+                int rank = 0;                                  // position of i in the key-sorted order (ties by index)
+                for (int j = 0; j < n; ++j) { const uint32_t kj = KEY[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+                if (rank < T) { so[3 * rank] = P[3 * i]; so[3 * rank + 1] = P[3 * i + 1]; so[3 * rank + 2] = P[3 * i + 2]; }
+            }
+        }
+    } else {
+        tcount = n;                                            // fewer points than the encoder subset: use them all
+        for (int t = tid; t < T; t += PREP_THREADS) {
+            const bool v = t < n;
+            so[3 * t] = v ? P[3 * t] : 0.f; so[3 * t + 1] = v ? P[3 * t + 1] : 0.f; so[3 * t + 2] = v ? P[3 * t + 2] : 0.f;
+        }
+    }
+    if (tid == 0) t_per_cloud[b] = tcount;
+
+    // ---- init_points: indices with replacement + gaussian noise, clamped ---------------------------------
+    const float lim = 0.5f * A.padding_scale;
+    float* io = init + (size_t)b * A.n_opt * 3;
+    for (int t = tid; t < A.n_opt; t += PREP_THREADS) {
+        int j;
+        float g0, g1, g2;
+        if (init_idx) {
+            j = init_idx[(size_t)b * A.n_opt + t];
+        } else {
+            const U4 r = philox(gcloud, (uint32_t)t, 2u, 0u, A.seed_lo, A.seed_hi);
+            j = (int)(((uint64_t)r.x * (uint64_t)n) >> 32);    // uniform in [0, n)
+        }
+        if (noise) {
+            const float* nz = noise + ((size_t)b * A.n_opt + t) * 3;
+            g0 = nz[0]; g1 = nz[1]; g2 = nz[2];
+        } else {
+            const U4 r = philox(gcloud, (uint32_t)t, 3u, 0u, A.seed_lo, A.seed_hi);
+            const float ra = sqrtf(-2.f * logf(u01(r.x))), rb = sqrtf(-2.f * logf(u01(r.z)));
+            float s0, c0, s1, c1;
+            sincosf(6.28318530717958647692f * u01(r.y), &s0, &c0);
+            sincosf(6.28318530717958647692f * u01(r.w), &s1, &c1);
+            g0 = ra * c0; g1 = ra * s0; g2 = rb * c1;
+        }
+        const float gs[3] = {g0, g1, g2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) io[3 * t + a] = fminf(fmaxf(P[3 * j + a] + gs[a] * A.init_sigma, -lim), lim);
+    }
+}
+
+constexpr size_t SOR_LDS = (5 * PREP_MAXK + 16) * sizeof(double);                       // 82,048 B
+constexpr size_t PREP_LDS = 3 * PREP_MAXK * 4 + PREP_MAXK * 4 + PREP_MAXK * 4 + 64 * 4;   // 41,216 B
+
+hipError_t configure_prep_kernels() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)SOR_LDS);
+}
+
+hipError_t launch_sor(const float* pc, int B, int K, int k_nn, double alpha, uint8_t* keep, double* value, hipStream_t s) {
+    hipLaunchKernelGGL(sor_kernel, dim3(B), dim3(PREP_THREADS), SOR_LDS, s, pc, K, k_nn, alpha, keep, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, const PrepArgs& a, const int32_t* sel_idx,
+                          const int32_t* init_idx, const float* noise, float* sel, int32_t* t_per_cloud, float* init,
+                          int32_t* n_kept, float* proc_out, hipStream_t s) {
+    hipLaunchKernelGGL(prepare_kernel, dim3(B), dim3(PREP_THREADS), PREP_LDS, s, pc, keep, K, a, sel_idx, init_idx, noise,
+                       sel, t_per_cloud, init, n_kept, proc_out);
+    return hipGetLastError();
+}
+
+}  // namespace ifd

@@ -1,0 +1,108 @@
+"""The defense driver: ``defend_point_cloud`` and the .npz in/out of ConvONet/opt_defense.py:255-369.
+
+Everything between the input array and the restored array runs on the GPU (SOR, preprocess, subset, encoder,
+init, 501-step optimiser, normalisation); the host only slices batches and copies the result back.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .runtime import Restorer
+
+
+@dataclass
+class DefenseArgs:
+    """Mirror of the reference's CLI namespace (ConvONet/opt_defense.py:21-61), same names and defaults."""
+    sample_npoint: int = 1024
+    padding_scale: float = 0.9
+    init_sigma: float = 0.01
+    iterations: int = 200
+    batch_size: int = 192
+    lr: float = 0.001
+    rep_weight: float = 500.0
+    sor: bool = True
+    sor_k: int = 2
+    sor_alpha: float = 1.1
+    threshold: float = 0.2          # cfg['test']['threshold']
+    input_npoint: int = 600         # cfg['data']['pointcloud_n']
+    seed: int = 0                   # extension: the reference is unseeded
+    chunk: int = 768                # extension: clouds per device pass (memory knob, does not change results)
+
+
+def defend_point_cloud(r: Restorer, pc, args: DefenseArgs, cloud_index_base: int = 0, total_clouds: Optional[int] = None,
+                       return_device: bool = False):
+    """defend_point_cloud(pc) (opt_defense.py:255-314): pc [N,K,3] (numpy or torch) -> restored [N,sample_npoint,3].
+
+    ``cloud_index_base`` / ``total_clouds`` place this call's clouds inside a larger (sharded) array: random
+    draws are keyed by the global cloud index and the 1/B loss factor (opt_defense.py:215,222) is that of the
+    reference batch (size ``batch_size``, the last one shorter) the cloud would have been in - so any sharding
+    gives bit-identical results.
+    """
+    x = torch.as_tensor(pc)[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
+    N = x.shape[0]
+    total = int(total_clouds if total_clouds is not None else cloud_index_base + N)
+    out = torch.empty(N, args.sample_npoint, 3, device=r.device, dtype=torch.float32)
+    bs = int(args.batch_size)
+    for lo in range(0, N, int(args.chunk)):
+        hi = min(N, lo + int(args.chunk))
+        xb = x[lo:hi]
+        keep = r.sor(xb, args.sor_k, args.sor_alpha) if args.sor else None
+        prep = r.prepare(xb, keep, n_sel=args.input_npoint, n_opt=args.sample_npoint, padding_scale=args.padding_scale,
+                         init_sigma=args.init_sigma, seed=args.seed, cloud_index_base=cloud_index_base + lo)
+        planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        # group by the reference batch each cloud belongs to (its size is the 1/B of both losses)
+        g0 = cloud_index_base + lo
+        s = lo
+        while s < hi:
+            gidx = cloud_index_base + s
+            batch_start = (gidx // bs) * bs
+            batch_len = min(bs, total - batch_start)
+            e = min(hi, s + (batch_start + batch_len - gidx))
+            out[s:e] = r.optimize_points(prep["init"][s - lo:e - lo], planes[s - lo:e - lo], rep_weight=args.rep_weight,
+                                         iterations=args.iterations, lr=args.lr, loss_batch=batch_len, normalize=True)
+            s = e
+        del planes, prep
+    return out if return_device else out.cpu().numpy()
+
+
+def get_save_name(path: str) -> str:
+    """opt_defense.py:242-252: <dir>/ConvONet-Opt/convonet_opt-<basename>."""
+    sub = path.split('/')
+    folder = os.path.join(path[:path.rindex(sub[-1])], 'ConvONet-Opt')
+    os.makedirs(folder, exist_ok=True)
+    return os.path.join(folder, 'convonet_opt-' + sub[-1])
+
+
+def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None) -> str:
+    """opt_defense.py:317-344: test_pc / test_label (/ target_label) in, same keys out (float32 / uint8)."""
+    npz = np.load(path)
+    test_pc = npz['test_pc'][..., :3]
+    test_label = npz['test_label']
+    target_label = npz['target_label'] if 'target_label' in npz.files else None
+    fn = defend or (lambda a: defend_point_cloud(r, a, args))
+    out = fn(test_pc)
+    save_path = get_save_name(path)
+    kw = dict(test_pc=out.astype(np.float32), test_label=test_label.astype(np.uint8))
+    if target_label is not None:
+        kw['target_label'] = target_label.astype(np.uint8)
+    np.savez(save_path, **kw)
+    print('defense result saved to {}'.format(save_path))
+    return save_path
+
+
+def defend_npz_train_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None) -> str:
+    """opt_defense.py:347-369 (--train=True): train_pc/train_label/test_pc/test_label."""
+    npz = np.load(path)
+    fn = defend or (lambda a: defend_point_cloud(r, a, args))
+    def_train = fn(npz['train_pc'][..., :3])
+    def_test = fn(npz['test_pc'][..., :3])
+    save_path = get_save_name(path)
+    np.savez(save_path, train_pc=def_train.astype(np.float32), train_label=npz['train_label'].astype(np.uint8),
+             test_pc=def_test.astype(np.float32), test_label=npz['test_label'].astype(np.uint8))
+    print('defense result saved to {}'.format(save_path))
+    return save_path

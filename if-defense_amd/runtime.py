@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import IfdConfig, IfdOptParams
+from ._lib import IfdConfig, IfdOptParams, IfdPrepParams
 
 PLANE_ORDER = ("xz", "xy", "yz")
 
@@ -82,6 +82,81 @@ class Restorer:
         if c.dim() != 5 or tuple(c.shape[1:]) != (3, 64, 64, 32):
             raise IfdError("planes must be [B,3,64,64,32] channel-last or the reference's dict of [B,32,64,64]")
         return c
+
+    # ---------------------------------------------------------------- pre-processing
+    def sor(self, pc: torch.Tensor, k: int = 2, alpha: float = 1.1, want_value: bool = False):
+        """SORDefense(k, alpha) keep-mask (defense/SOR.py:22-49): pc [B,K,3] -> uint8 [B,K] (and float64 value)."""
+        pc = _f32(pc, self.device)
+        B, K = pc.shape[:2]
+        keep = torch.empty(B, K, device=self.device, dtype=torch.uint8)
+        val = torch.empty(B, K, device=self.device, dtype=torch.float64) if want_value else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_sor(self.ctx, pc.data_ptr(), B, K, int(k), float(alpha), keep.data_ptr(),
+                                         self._ptr(val), self._stream()))
+        return (keep, val) if want_value else keep
+
+    def prepare(self, pc: torch.Tensor, keep: Optional[torch.Tensor] = None, n_sel: int = 600, n_opt: int = 1024,
+                padding_scale: float = 0.9, init_sigma: float = 0.01, seed: int = 0, cloud_index_base: int = 0,
+                sel_idx: Optional[torch.Tensor] = None, init_idx: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None, want_proc: bool = False):
+        """preprocess_pc + init_points (opt_defense.py:114-179) for a batch.  Returns a dict with
+        sel [B,n_sel,3], t_per_cloud [B], init [B,n_opt,3], n_kept [B] (and proc [B,K,3] if asked)."""
+        pc = _f32(pc, self.device)
+        B, K = pc.shape[:2]
+        i32 = lambda t: None if t is None else t.to(device=self.device, dtype=torch.int32).contiguous()
+        sel_idx, init_idx = i32(sel_idx), i32(init_idx)
+        noise = None if noise is None else _f32(noise, self.device)
+        keep = None if keep is None else keep.to(device=self.device, dtype=torch.uint8).contiguous()
+        sel = torch.empty(B, n_sel, 3, device=self.device, dtype=torch.float32)
+        tpc = torch.empty(B, device=self.device, dtype=torch.int32)
+        init = torch.empty(B, n_opt, 3, device=self.device, dtype=torch.float32)
+        nk = torch.empty(B, device=self.device, dtype=torch.int32)
+        proc = torch.zeros(B, K, 3, device=self.device, dtype=torch.float32) if want_proc else None
+        prm = IfdPrepParams(C.sizeof(IfdPrepParams), int(n_sel), int(n_opt), float(padding_scale), float(init_sigma),
+                            int(seed) & 0xFFFFFFFFFFFFFFFF, int(cloud_index_base))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_prepare(self.ctx, pc.data_ptr(), self._ptr(keep), B, K, C.byref(prm),
+                                             self._ptr(sel_idx), self._ptr(init_idx), self._ptr(noise), sel.data_ptr(),
+                                             tpc.data_ptr(), init.data_ptr(), nk.data_ptr(), self._ptr(proc),
+                                             self._stream()))
+        out = {"sel": sel, "t_per_cloud": tpc, "init": init, "n_kept": nk}
+        if want_proc:
+            out["proc"] = proc
+        return out
+
+    # ---------------------------------------------------------------- encoder
+    def encode_points(self, sel: torch.Tensor, t_per_cloud: Optional[torch.Tensor] = None, want_c: bool = False):
+        """Point-wise half of encode_inputs (pointnet.py:124-156 + scatter_mean): sel [B,T,3] -> pre-U-Net
+        planes [B,3,64,64,32] channel-last (and the per-point features c [B,T,32])."""
+        sel = _f32(sel, self.device)
+        B, T = sel.shape[:2]
+        tpc = None if t_per_cloud is None else t_per_cloud.to(device=self.device, dtype=torch.int32).contiguous()
+        pre = torch.empty(B, 3, 64, 64, 32, device=self.device, dtype=torch.float32)
+        c = torch.empty(B, T, 32, device=self.device, dtype=torch.float32) if want_c else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_encode_points(self.ctx, sel.data_ptr(), self._ptr(tpc), B, T, pre.data_ptr(),
+                                                   self._ptr(c), self._stream()))
+        return (pre, c) if want_c else pre
+
+    def encode_inputs(self, sel: torch.Tensor, t_per_cloud: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """generator.model.encode_inputs(x) (opt_defense.py:300): [B,T,3] -> planes [B,3,64,64,32] channel-last
+        (use planes_from_channel_last for the reference's dict of [B,32,64,64])."""
+        sel = _f32(sel, self.device)
+        B, T = sel.shape[:2]
+        tpc = None if t_per_cloud is None else t_per_cloud.to(device=self.device, dtype=torch.int32).contiguous()
+        planes = torch.empty(B, 3, 64, 64, 32, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_encode_planes(self.ctx, sel.data_ptr(), self._ptr(tpc), B, T, planes.data_ptr(),
+                                                   self._stream()))
+        return planes
+
+    def unet(self, planes_pre: torch.Tensor) -> torch.Tensor:
+        """The shared U-Net on pre-U-Net planes [B,3,64,64,32] (src/encoder/unet.py:225-239)."""
+        pre = _f32(planes_pre, self.device)
+        out = torch.empty_like(pre)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_unet(self.ctx, pre.data_ptr(), pre.shape[0], out.data_ptr(), self._stream()))
+        return out
 
     # ---------------------------------------------------------------- call seams
     def decode(self, p: torch.Tensor, c, want_grad: bool = False):

@@ -85,6 +85,57 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
 void     ifd_destroy(ifd_ctx* ctx);
 const char* ifd_last_error(const ifd_ctx* ctx);   /* ctx may be NULL: error of the last failed ifd_create */
 
+/* ---- pre-processing ------------------------------------------------------------ */
+
+/* sor_process / SORDefense.outlier_removal (ConvONet/opt_defense.py:86-111, defense/SOR.py:22-49):
+ * pc [B,K,3] -> keep_mask [B,K] (1 = kept: value <= mean + alpha * std, float64 like the reference);
+ * value (optional) [B,K] float64 = mean of the k nearest squared distances.  2 <= K <= 2048, k <= 7. */
+int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uint8_t* keep_mask,
+            double* value, void* stream);
+
+typedef struct ifd_prep_params {
+    int32_t  struct_size;      /* sizeof(ifd_prep_params) */
+    int32_t  n_sel;            /* cfg data.pointcloud_n: encoder subset size, 600 */
+    int32_t  n_opt;            /* --sample_npoint: optimised points per cloud, 1024 */
+    float    padding_scale;    /* --padding_scale, 0.9 */
+    float    init_sigma;       /* --init_sigma, 0.01 */
+    uint64_t seed;             /* the reference never seeds; draws here = f(seed, global cloud index, draw index) */
+    int64_t  cloud_index_base; /* global index of cloud 0 of this call (sharding-invariant random draws) */
+} ifd_prep_params;
+
+/* preprocess_pc + init_points (ConvONet/opt_defense.py:114-146, 149-179) on the points SOR kept.
+ * keep_mask may be NULL (--sor=False).  Explicit draws (all optional, for parity tests): sel_idx [B,n_sel]
+ * (np.random.choice without replacement), init_idx [B,n_opt] (torch.randint), noise [B,n_opt,3] ~ N(0,1).
+ * Outputs: sel [B,n_sel,3] (rows >= t_per_cloud[b] are zero), t_per_cloud [B] = min(n_kept, n_sel),
+ * init_points [B,n_opt,3], n_kept (optional) [B], proc (optional) [B,K,3]: the processed kept points,
+ * first n_kept[b] rows valid.  K <= 2048, n_sel <= 1024. */
+int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, int K, const ifd_prep_params* prm,
+                const int32_t* sel_idx, const int32_t* init_idx, const float* noise, float* sel,
+                int32_t* t_per_cloud, float* init_points, int32_t* n_kept, float* proc, void* stream);
+
+/* ---- encoder ------------------------------------------------------------------ */
+
+/* Point-wise half of generator.model.encode_inputs (ConvONet/opt_defense.py:300 ->
+ * src/encoder/pointnet.py:124-156 + generate_plane_features :68-80 up to, not including, the U-Net):
+ * fc_pos, 5 ResnetBlockFC with pool_local (scatter_max/gather over the 3 planes), fc_c, scatter_mean.
+ * sel [B,Tmax,3] (the 600-point encoder subsets); t_per_cloud [B] int32 or NULL (= Tmax for every cloud):
+ * clouds may hold fewer than Tmax valid points (the reference's torch.cat at :284 cannot express that).
+ * planes_pre [B,3,64,64,32] channel-last, fully written (zero where no point falls).
+ * c_points (optional) [B,Tmax,32]: the per-point features c.   1 <= Tmax <= 1024. */
+int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax,
+                      float* planes_pre, float* c_points, void* stream);
+
+/* The shared 2-D U-Net applied to the three planes of every cloud (pointnet.py:82-84 -> src/encoder/unet.py:225-239):
+ * planes_pre [B,3,64,64,32] -> planes [B,3,64,64,32], both channel-last.  Uses context-owned scratch
+ * (about 15 MB per cloud, grown on demand). */
+int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* stream);
+
+/* generator.model.encode_inputs(x) (ConvONet/opt_defense.py:300 -> src/conv_onet/models/__init__.py:52 ->
+ * LocalPoolPointnet.forward): ifd_encode_points followed by ifd_unet.  sel [B,Tmax,3], t_per_cloud as above,
+ * planes [B,3,64,64,32] channel-last = {'xz','xy','yz': [B,32,64,64]} of the reference, permuted. */
+int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax,
+                      float* planes, void* stream);
+
 /* ---- decoder / losses / optimiser: the 501-step hot loop --------------------- */
 
 /* generator.model.decode(p, c).logits (ConvONet/opt_defense.py:212 ->

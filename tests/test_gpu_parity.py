@@ -209,3 +209,126 @@ def test_bad_arguments_return_errors(restorer, planes2):
         restorer.repulsion_loss(torch.zeros(1, 5, 3))                                  # K < 6
     with pytest.raises(I.IfdError):
         restorer.decode(torch.zeros(1, 8, 3), torch.zeros(1, 3, 64, 64, 16))
+
+
+# ---------------------------------------------------------------------------------------------------
+# pre-processing + encoder (rows A3-A8 of SURVEY section 8a)
+# ---------------------------------------------------------------------------------------------------
+def test_sor_mask_bit_exact(restorer, golden):
+    keep, val = restorer.sor(torch.from_numpy(golden["raw"]), 2, 1.1, want_value=True)
+    assert np.array_equal(keep.cpu().numpy().astype(bool), golden["sor_keep"])       # boolean work: bit-exact
+    np.testing.assert_allclose(val.cpu().numpy(), golden["sor_value"], rtol=1e-9, atol=1e-18)
+
+
+def test_sor_edge_sizes(restorer):
+    from oracle import convonet_oracle as O
+    g = torch.Generator().manual_seed(11)
+    for K in (8, 100, 1024, 1500, 2048):
+        pc = torch.randn(2, K, 3, generator=g)
+        ref, _ = O.sor_keep_mask(pc)
+        got = restorer.sor(pc).cpu().numpy().astype(bool)
+        assert (got == ref.numpy()).mean() > 0.9995, K              # fp64 threshold ties only
+
+
+def test_prepare_with_recorded_draws(restorer, golden):
+    out = restorer.prepare(torch.from_numpy(golden["raw"]), torch.from_numpy(golden["sor_keep"].astype(np.uint8)),
+                           sel_idx=torch.from_numpy(golden["sel_idx"]), init_idx=torch.from_numpy(golden["init_idx"]),
+                           noise=torch.from_numpy(golden["noise"]), want_proc=True)
+    assert out["n_kept"].cpu().tolist() == golden["proc_len"].tolist()
+    assert out["t_per_cloud"].cpu().tolist() == [600] * 4
+    proc = out["proc"].cpu().numpy()
+    for b in range(4):
+        n = golden["proc_len"][b]
+        np.testing.assert_allclose(proc[b, :n], golden["proc_pad"][b, :n], rtol=0, atol=2e-7)
+        sel_ref = golden["proc_pad"][b][golden["sel_idx"][b]]
+        np.testing.assert_allclose(out["sel"][b].cpu().numpy(), sel_ref, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(out["init"].cpu().numpy(), golden["init_points"], rtol=0, atol=3e-7)
+
+
+def test_prepare_random_draws_are_valid_and_shard_invariant(restorer, golden):
+    raw = torch.from_numpy(golden["raw"])
+    keep = torch.from_numpy(golden["sor_keep"].astype(np.uint8))
+    a = restorer.prepare(raw, keep, seed=7, cloud_index_base=10, want_proc=True)
+    b0 = restorer.prepare(raw[:1], keep[:1], seed=7, cloud_index_base=10)
+    b1 = restorer.prepare(raw[1:], keep[1:], seed=7, cloud_index_base=11)
+    assert torch.equal(a["sel"], torch.cat([b0["sel"], b1["sel"]]))           # draws keyed by the global cloud index
+    assert torch.equal(a["init"], torch.cat([b0["init"], b1["init"]]))
+    c = restorer.prepare(raw, keep, seed=8, cloud_index_base=10)
+    assert not torch.equal(a["sel"], c["sel"])
+    proc, sel, init = a["proc"].cpu().numpy(), a["sel"].cpu().numpy(), a["init"].cpu().numpy()
+    for bb in range(4):
+        n = int(a["n_kept"][bb])
+        rows = {tuple(np.round(v, 6)) for v in proc[bb, :n]}
+        got = [tuple(np.round(v, 6)) for v in sel[bb]]
+        assert len(set(got)) == 600 and set(got) <= rows                      # a subset without replacement
+    assert np.abs(init).max() <= 0.45 + 1e-7
+    d = init[0][:, None, :] - proc[0][None, :int(a["n_kept"][0]), :]
+    nn = np.sqrt((d ** 2).sum(-1)).min(1)                                     # every init point = a cloud point + noise
+    assert 0.010 < nn.mean() < 0.03 and nn.max() < 0.08
+
+
+def test_prepare_sparse_cloud_fewer_than_subset(restorer):
+    """Drop-attack regime: fewer points than the 600-point encoder subset -> use them all (ragged)."""
+    g = torch.Generator().manual_seed(2)
+    pc = torch.randn(3, 256, 3, generator=g)
+    out = restorer.prepare(pc, None)
+    assert out["t_per_cloud"].cpu().tolist() == [256] * 3 and out["n_kept"].cpu().tolist() == [256] * 3
+    assert float(out["sel"][:, 256:].abs().max()) == 0.0
+    planes = restorer.encode_inputs(out["sel"], out["t_per_cloud"])
+    assert torch.isfinite(planes).all()
+
+
+def test_encoder_pointnet_and_scatter_mean(restorer, golden):
+    proc = [golden["proc_pad"][b, :golden["proc_len"][b]] for b in range(4)]
+    sel = torch.from_numpy(np.stack([proc[b][golden["sel_idx"][b]] for b in range(4)]))
+    pre, c = restorer.encode_points(sel, want_c=True)
+    assert _rel(c.cpu().numpy(), golden["enc_c"]) < 1e-5
+    pre_xz0 = pre[0, 0].permute(2, 0, 1).cpu().numpy()                         # [32,64,64] like the reference
+    assert _rel(pre_xz0, golden["enc_pre_xz0"]) < 1e-5
+    assert (pre_xz0 != 0).any(axis=0).sum() == (golden["enc_pre_xz0"] != 0).any(axis=0).sum()   # same occupied cells
+
+
+def test_encoder_planes_match_reference(restorer, golden):
+    import ifdefense_amd as I
+    proc = [golden["proc_pad"][b, :golden["proc_len"][b]] for b in range(4)]
+    sel = torch.from_numpy(np.stack([proc[b][golden["sel_idx"][b]] for b in range(4)]))
+    planes = I.planes_from_channel_last(restorer.encode_inputs(sel))
+    for i, pl in enumerate(PL):
+        ref = golden["planes01"][:, i]
+        assert _rel(planes[pl][:2].cpu().numpy(), ref) < 2e-4, pl
+        for b in range(4):
+            assert abs(float(planes[pl][b].abs().mean()) - golden["planes_stats"][b, i, 1]) < 1e-4
+
+
+def test_encoder_ragged_matches_dense(restorer, golden):
+    """t_per_cloud < T must equal encoding the shorter cloud alone (no cross-sample ops in the encoder)."""
+    proc = golden["proc_pad"][0, :golden["proc_len"][0]]
+    sel = torch.zeros(2, 600, 3)
+    sel[0] = torch.from_numpy(proc[:600])
+    sel[1, :300] = torch.from_numpy(proc[:300])
+    a = restorer.encode_points(sel, torch.tensor([600, 300]))
+    b = restorer.encode_points(sel[1:, :300])
+    assert torch.equal(a[1], b[0])
+
+
+def test_defend_point_cloud_end_to_end_and_sharding(restorer, golden):
+    import ifdefense_amd as I
+    args = I.DefenseArgs(iterations=30, batch_size=3, seed=3)
+    raw = golden["raw"]
+    full = I.defend_point_cloud(restorer, raw, args)
+    assert full.shape == (4, 1024, 3) and full.dtype == np.float32 and np.isfinite(full).all()
+    np.testing.assert_allclose(np.linalg.norm(full, axis=-1).max(axis=1), 1.0, rtol=1e-6)
+    lo = I.defend_point_cloud(restorer, raw[:1], args, cloud_index_base=0, total_clouds=4)
+    hi = I.defend_point_cloud(restorer, raw[1:], args, cloud_index_base=1, total_clouds=4)
+    assert np.array_equal(np.concatenate([lo, hi]), full)                     # P4: shard + concatenate is bitwise
+    small = I.defend_point_cloud(restorer, raw, I.DefenseArgs(iterations=30, batch_size=3, seed=3, chunk=1))
+    assert np.array_equal(small, full)                                         # the memory knob does not change results
+
+
+def test_unet_matches_reference_and_is_batch_invariant(restorer, golden):
+    pre = torch.from_numpy(golden["enc_pre_xz0"]).permute(1, 2, 0)[None, None].repeat(1, 3, 1, 1, 1).contiguous()
+    out = restorer.unet(pre)                                                    # [1,3,64,64,32]
+    got = out[0, 0].permute(2, 0, 1).cpu().numpy()
+    assert _rel(got, golden["planes01"][0, 0]) < 2e-5
+    big = restorer.unet(torch.cat([torch.randn(2, 3, 64, 64, 32), pre, torch.randn(3, 3, 64, 64, 32)]))
+    assert torch.equal(big[2], out[0])                                          # fixed summation order: batch-size independent
