@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the ConvONet-Opt restoration path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the whole hot path (SOR -> preprocess/subset/init -> encoder -> 501 Adam steps ->
+normalise -> all-gather) over one batch of synthetic ModelNet40-test-like input: 2468 clouds x 1024 points per
+GPU (BASELINE.json configs[1]; weak scaling: every rank restores its own 2468 clouds of a 2468*N array).
+Inputs are resident in HBM when the timed region starts; weights are seeded random (the trained checkpoint
+and ModelNet40 are downloads).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CLOUDS = 2468          # ModelNet40 test-set size
+K_POINTS = 1024
+ITERATIONS = 500         # -> 501 Adam steps (opt_defense.py:210)
+FLOP_DENSE_PER_CLOUD = 2 * 15488 * 2 * K_POINTS * (ITERATIONS + 1)     # decoder fwd + input-bwd, SURVEY 8d
+F32_MFMA_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md
+
+
+def synth_clouds(n, seed=1234):
+    """Area-uniform samples of 7 shape families, unit-sphere normalised like ModelNet40 inputs."""
+    rng = np.random.default_rng(seed)
+    air = np.load(os.path.join(ROOT, "tests", "golden", "convonet_golden.npz"))["raw"][0]
+    out = np.empty((n, K_POINTS, 3), np.float32)
+
+    def unit(v):
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    def box(ext, m):
+        ext = np.asarray(ext, np.float64)
+        area = np.array([ext[1] * ext[2], ext[0] * ext[2], ext[0] * ext[1]])
+        ax = rng.choice(3, m, p=area / area.sum())
+        p = rng.uniform(-1, 1, (m, 3)) * ext
+        p[np.arange(m), ax] = rng.choice([-1.0, 1.0], m) * ext[ax]
+        return p
+
+    for i in range(n):
+        kind = i % 7
+        if kind == 0:
+            p = unit(rng.standard_normal((K_POINTS, 3)))
+        elif kind == 1:
+            p = unit(rng.standard_normal((K_POINTS, 3))) * rng.uniform(0.4, 1.0, 3)
+        elif kind == 2:
+            p = box(rng.uniform(0.3, 1.0, 3), K_POINTS)
+        elif kind == 3:
+            a, h = rng.uniform(0, 2 * np.pi, K_POINTS), rng.uniform(-1, 1, K_POINTS)
+            r = rng.uniform(0.3, 0.8)
+            p = np.stack([r * np.cos(a), r * np.sin(a), h], 1)
+        elif kind == 4:
+            a, b = rng.uniform(0, 2 * np.pi, (2, K_POINTS))
+            t = rng.uniform(0.2, 0.4)
+            p = np.stack([(1 + t * np.cos(b)) * np.cos(a), (1 + t * np.cos(b)) * np.sin(a), t * np.sin(b)], 1)
+        elif kind == 5:
+            m = K_POINTS // 2
+            p = np.concatenate([box([0.5, 0.5, 0.08], m), box([0.5, 0.08, 0.5], K_POINTS - m) + [0, 0.45, 0.45]])
+        else:
+            th = rng.uniform(0, 2 * np.pi)
+            rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+            p = air @ rot.T
+        p = p - p.mean(0)
+        out[i] = (p / np.linalg.norm(p, axis=1).max()).astype(np.float32)
+    return out
+
+
+def cpu_baseline(clouds, n_sample=16, n_steps=50):
+    """The CPU oracle (a port of the reference's op sequence: bmm-kNN + topk, autograd, torch.optim.Adam) timed
+    on the host cores on a bounded sample, scaled to 501 steps.  Reported next to the GPU number, not a target."""
+    from oracle import convonet_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    w = O.to_torch(O.make_random_weights(0))
+    x = torch.from_numpy(clouds[:n_sample])
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    keep, _ = O.sor_keep_mask(x)
+    proc = [O.preprocess_pc(clouds[b][keep[b].numpy()]) for b in range(n_sample)]
+    sel = torch.from_numpy(np.stack([p[rng.choice(len(p), 600, replace=False)] for p in proc]))
+    with torch.no_grad():
+        planes = O.encode_inputs(w, sel)
+    idx = np.stack([rng.integers(0, len(p), K_POINTS) for p in proc])
+    init = O.init_points(proc, idx, rng.standard_normal((n_sample, K_POINTS, 3)).astype(np.float32))
+    t_pre = time.perf_counter() - t0
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=0, normalize=False)       # warm
+    t0 = time.perf_counter()
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=n_steps - 1, normalize=True)
+    t_opt = time.perf_counter() - t0
+    per_cloud = (t_pre + t_opt / n_steps * (ITERATIONS + 1)) / n_sample
+    return {"value": round(1.0 / per_cloud, 4), "unit": "clouds/s", "cores": threads, "kind": "port",
+            "sample": "%d clouds: SOR+preprocess+encoder once (%.2f s) + %d of %d Adam steps (%.2f s), scaled to %d steps"
+                      % (n_sample, t_pre, n_steps, ITERATIONS + 1, t_opt, ITERATIONS + 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clouds", type=int, default=N_CLOUDS, help="clouds per GPU per step (default: MN40 test size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import ifdefense_amd as I
+    from ifdefense_amd import dist as D
+    import torch.distributed as dist
+
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (a.gpus, world))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    total = a.clouds * world
+    all_clouds = synth_clouds(total)
+    lo, hi, per = D.shard_range(total, rank, world)
+    x = torch.from_numpy(all_clouds[lo:hi]).to(dev)                     # resident in HBM before timing
+    r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device=dev)
+    args = I.DefenseArgs(iterations=ITERATIONS, seed=1234)
+
+    # time the dominant kernel (the persistent optimiser) with events on the stream it is launched on
+    ev = []
+    orig = r.optimize_points
+
+    def timed_optimize(*p, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(*p, **k)
+        e1.record()
+        ev.append((e0, e1, out.shape[0]))
+        return out
+
+    r.optimize_points = timed_optimize
+
+    def step():
+        local_out = I.defend_point_cloud(r, x, args, cloud_index_base=lo, total_clouds=total, return_device=True)
+        return D.gather_shards(local_out, total, per)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    ev.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert out.shape == (total, K_POINTS, 3) and bool(torch.isfinite(out).all())
+
+    kern_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+    kern_clouds = [n for _, _, n in ev]
+    if rank == 0:
+        avg_ms = sum(kern_ms) / len(kern_ms)
+        avg_clouds = sum(kern_clouds) / len(kern_clouds)
+        achieved = FLOP_DENSE_PER_CLOUD * avg_clouds / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("optimize_kernel_hbm_bytes_per_launch")
+        res = {
+            "metric": "restored clouds/sec (1024-pt ModelNet40, ConvONet-Opt 500 iters)",
+            "value": round(total * a.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ConvONet-Opt on ModelNet40-test-like .npz: %d clouds/GPU x 1024 pts, --iterations=500 "
+                                   "(501 Adam steps), SOR on, batch_size 192; SOR+preprocess+encode+init+optimise+"
+                                   "normalise+gather" % a.clouds,
+                       "clouds_per_gpu": a.clouds, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
+                       "parallelism": "shard%d+allgather" % world, "weights": "seeded random (seed 0)"},
+            "roofline": {"bound": "mfma", "kernel": "ifd::optimize_kernel", "achieved": round(achieved, 2),
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": traffic, "launch_ms": round(avg_ms, 2), "clouds_per_launch": avg_clouds,
+                         "flop_per_cloud": FLOP_DENSE_PER_CLOUD},
+            "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(all_clouds)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,7 @@ SIGNATURES = {
     "ifd_repulsion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "ifd_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
-                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ifd_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ifd_normalize_unit_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -365,8 +365,8 @@ int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_repulsion launch", e);
 }
 
-int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, const ifd_opt_params* prm, float* m,
-                 float* v, float* loss, void* stream) {
+int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, const ifd_opt_params* prm,
+                 const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 1024)");
@@ -384,7 +384,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
     e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset", e);
-    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K,
+    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K,
                         a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
 }

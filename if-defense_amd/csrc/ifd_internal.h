@@ -45,7 +45,7 @@ hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, co
 
 hipError_t configure_optimize_kernels();
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                           uint16_t* knn_lists, unsigned long long* counters, int B, int K, const OptArgs& a,
+                           const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters, int B, int K, const OptArgs& a,
                            hipStream_t s);
 // bytes of context workspace ifd_optimize needs for B clouds (certified neighbour lists)
 size_t knn_list_bytes(int B);

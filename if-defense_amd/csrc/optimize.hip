@@ -558,7 +558,8 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
-    float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out, uint16_t* knn_lists,
+    float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
+    const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
     unsigned long long* __restrict__ counters, int K, OptArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
@@ -597,8 +598,9 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
 
     const DecConst dc = A.dc;
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
-    const float inv_lb = 1.0f / (float)A.loss_batch;
-    const float rep_scale = A.rep_weight / ((float)A.loss_batch * (float)K * 5.f);
+    const int loss_batch = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : A.loss_batch;
+    const float inv_lb = 1.0f / (float)loss_batch;
+    const float rep_scale = A.rep_weight / ((float)loss_batch * (float)K * 5.f);
     const bool use_rep = A.rep_weight > 0.f;
     double b1t = pow(0.9, (double)A.t0), b2t = pow(0.999, (double)A.t0);
     float rep_loss_a = 0.f, rep_loss_b = 0.f;
@@ -887,10 +889,10 @@ hipError_t configure_optimize_kernels() {
 }
 
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
-                           float* loss, uint16_t* knn_lists, unsigned long long* counters, int B, int K,
-                           const OptArgs& a, hipStream_t s) {
+                           float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
+                           unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(optimize_kernel, dim3(B), dim3(OPT_THREADS), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                       knn_lists, counters, K, a);
+                       loss_batch_per_cloud, knn_lists, counters, K, a);
     return hipGetLastError();
 }
 

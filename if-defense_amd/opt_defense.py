@@ -1,0 +1,146 @@
+"""Optimizing input init points to object surface - MI355X build of ConvONet/opt_defense.py.
+
+Same flags, same defaults, same .npz in/out as the reference CLI (ConvONet/opt_defense.py:21-55,317-387), so
+restored clouds drop into baselines/inference.py unchanged:
+
+    python -m ifdefense_amd.opt_defense --data_root=path/to/adv_data.npz --iterations=500
+
+Differences, all additive: --seed (the reference is unseeded), --weights overrides cfg test.model_file,
+and under torchrun the clouds of each file are sharded over the ranks and all-gathered (rank 0 writes).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import yaml
+
+
+def str2bool(v):
+    return v.lower() in ("yes", "true", "t", "1")
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Extract meshes from occupancy process.')
+    parser.add_argument('--config', type=str, default='configs/convonet_3plane_mn40.yaml', help='Path to config file.')
+    parser.add_argument('--sample_npoint', type=int, default=1024, help='Re-sample points number per mesh.')
+    parser.add_argument('--padding_scale', type=float, default=0.9,
+                        help='Used in pre-processing point clouds, padding in unit cube')
+    parser.add_argument('--data_root', type=str, default='', help='Path to point cloud npz file.')
+    parser.add_argument('--train', type=str2bool, default=False, help='whether defend training data')
+    parser.add_argument('--init_sigma', type=float, default=0.01, help='sigma for normal dist used in ori_init')
+    parser.add_argument('--iterations', type=int, default=200, help='Optimization iterations.')
+    parser.add_argument('--batch_size', type=int, default=192, help='Batch process points.')
+    parser.add_argument('--lr', type=float, default=0.001, help='lr in optimization')
+    parser.add_argument('--rep_weight', type=float, default=500., help='loss weight for repulsion term')
+    parser.add_argument('--sor', type=str2bool, default=True, help='whether use SOR before reconstruction')
+    parser.add_argument('--sor_k', type=int, default=2, help='KNN in SOR')
+    parser.add_argument('--sor_alpha', type=float, default=1.1, help='Threshold = mean + alpha * std')
+    # additions
+    parser.add_argument('--seed', type=int, default=0, help='seed of the counter-based random draws')
+    parser.add_argument('--weights', type=str, default='', help='checkpoint (.pth); default: cfg test.model_file')
+    return parser
+
+
+# The shipped configuration, used when --config does not exist on disk (resolved values of
+# ConvONet/configs/convonet_3plane_mn40.yaml merged over configs/default.yaml).
+DEFAULT_CFG = {
+    'data': {'pointcloud_n': 600, 'padding': 0.1, 'dim': 3},
+    'model': {'encoder': 'pointnet_local_pool', 'decoder': 'simple_local', 'c_dim': 32,
+              'encoder_kwargs': {'hidden_dim': 32, 'plane_type': ['xz', 'xy', 'yz'], 'plane_resolution': 64,
+                                 'unet': True, 'unet_kwargs': {'depth': 4, 'merge_mode': 'concat', 'start_filts': 32}},
+              'decoder_kwargs': {'sample_mode': 'bilinear', 'hidden_size': 32}},
+    'test': {'threshold': 0.2, 'model_file': 'pretrain/convonet.pth'},
+}
+
+
+def _merge(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = v
+
+
+def load_config(path, default_path=None):
+    """src/config.py:11-38 (inherit_from / default merge) with yaml.safe_load (the reference's bare yaml.load
+    raises on PyYAML >= 6)."""
+    if not os.path.exists(path):
+        return DEFAULT_CFG
+    with open(path) as f:
+        special = yaml.safe_load(f) or {}
+    inherit = special.get('inherit_from')
+    if inherit is not None:
+        cfg = load_config(inherit, default_path)
+    elif default_path is not None and os.path.exists(default_path):
+        with open(default_path) as f:
+            cfg = yaml.safe_load(f) or {}
+    else:
+        cfg = {}
+    base = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULT_CFG.items()}
+    _merge(base, cfg)
+    _merge(base, special)
+    return base
+
+
+def check_supported(cfg):
+    m, ek = cfg['model'], cfg['model'].get('encoder_kwargs', {})
+    ok = (m.get('encoder') == 'pointnet_local_pool' and m.get('decoder') == 'simple_local' and m.get('c_dim') == 32 and
+          ek.get('hidden_dim') == 32 and ek.get('plane_resolution') == 64 and
+          sorted(ek.get('plane_type', [])) == ['xy', 'xz', 'yz'] and ek.get('unet') and
+          ek.get('unet_kwargs', {}).get('depth') == 4 and ek.get('unet_kwargs', {}).get('start_filts') == 32 and
+          m.get('decoder_kwargs', {}).get('hidden_size') == 32 and
+          m.get('decoder_kwargs', {}).get('sample_mode', 'bilinear') == 'bilinear')
+    if not ok:
+        raise SystemExit("unsupported model config: only the shipped 3-plane ConvONet "
+                         "(configs/convonet_3plane_mn40.yaml) is built for MI355X")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    cfg = load_config(args.config, 'configs/default.yaml')
+    check_supported(cfg)
+
+    import torch
+    from . import DefenseArgs, Restorer, defend_npz_test_data, defend_npz_train_test_data, defend_point_cloud, weights
+    from . import dist as D
+
+    rank, world, local = D.init_from_env()
+    device = torch.device('cuda', local)
+    wpath = args.weights or cfg['test']['model_file']
+    r = Restorer(weights.load_checkpoint(wpath), device=device, padding=cfg['data'].get('padding', 0.1),
+                 threshold=cfg['test']['threshold'])
+    dargs = DefenseArgs(sample_npoint=args.sample_npoint, padding_scale=args.padding_scale, init_sigma=args.init_sigma,
+                        iterations=args.iterations, batch_size=args.batch_size, lr=args.lr, rep_weight=args.rep_weight,
+                        sor=args.sor, sor_k=args.sor_k, sor_alpha=args.sor_alpha, threshold=cfg['test']['threshold'],
+                        input_npoint=cfg['data']['pointcloud_n'], seed=args.seed)
+
+    def defend(pc):
+        out = D.defend_sharded(lambda shard, base, total: defend_point_cloud(r, shard, dargs, base, total,
+                                                                             return_device=True), pc)
+        return out.cpu().numpy()
+
+    def one_file(path):
+        fn = defend_npz_train_test_data if args.train else defend_npz_test_data
+        if rank == 0:
+            fn(r, path, dargs, defend=defend)
+        else:                                   # non-zero ranks compute their shards, rank 0 writes the file
+            npz = np.load(path)
+            for key in (('train_pc', 'test_pc') if args.train else ('test_pc',)):
+                defend(npz[key][..., :3])
+
+    data_root = args.data_root
+    if not args.train and os.path.isdir(data_root):
+        for file in sorted(os.listdir(data_root)):       # (the reference iterates os.listdir order)
+            one = os.path.join(data_root, file)
+            if os.path.isfile(one):
+                one_file(one)
+    else:
+        one_file(data_root)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -185,7 +185,7 @@ class Restorer:
         return out if len(out) > 1 else loss
 
     def optimize_points(self, opt_points: torch.Tensor, c, rep_weight: float = 1.0, iterations: int = 1000,
-                        lr: float = 1e-3, loss_batch: Optional[int] = None, normalize: bool = True,
+                        lr: float = 1e-3, loss_batch=None, normalize: bool = True,
                         state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
                         return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
                         knn_scan_every_step: bool = False):
@@ -193,7 +193,7 @@ class Restorer:
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
         is given.  ``loss_batch`` is the reference batch size whose 1/B factor scales both losses
-        (default: the number of clouds passed in).  ``state=(m, v, t0)`` resumes / teacher-forces.
+        (default: the number of clouds passed in); an int, or an int32 tensor [B] with one value per cloud.  ``state=(m, v, t0)`` resumes / teacher-forces.
         Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
         is left to the caller.
         """
@@ -208,12 +208,19 @@ class Restorer:
         elif return_state:
             m, v = torch.zeros_like(p), torch.zeros_like(p)
         loss = torch.empty(B, 2, device=self.device, dtype=torch.float32) if return_loss else None
+        lb_arr = None
+        if torch.is_tensor(loss_batch):
+            lb_arr = loss_batch.to(device=self.device, dtype=torch.int32).contiguous()
+            if lb_arr.numel() != B:
+                raise IfdError("loss_batch tensor must have one entry per cloud")
+            loss_batch = B
         prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
                            float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12,
                            int(bool(knn_scan_every_step)))
         with torch.cuda.device(self.device):
             self._check(self.lib.ifd_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
-                                              self._ptr(m), self._ptr(v), self._ptr(loss), self._stream()))
+                                              self._ptr(lb_arr), self._ptr(m), self._ptr(v), self._ptr(loss),
+                                              self._stream()))
         out = (p,)
         if return_state:
             out += ((m, v, t0 + n_steps),)

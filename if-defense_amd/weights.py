@@ -68,3 +68,54 @@ def load_checkpoint(path: str) -> np.ndarray:
     if isinstance(sd, dict) and "model" in sd and "decoder.fc_p.weight" not in sd:
         sd = sd["model"]
     return pack_state_dict(sd)
+
+
+def random_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random weights of the shipped architecture (benchmarks / smoke runs; the trained
+    pretrain/convonet.pth is a Google-Drive download).  Linear layers: U(-1/sqrt(fan_in), +); convs:
+    Xavier-normal with a small uniform bias; fc_1 is NOT zero-initialised (src/layers.py:37 would make
+    every residual branch constant)."""
+    import math
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    def linear(name, n_out, n_in, bias=True):
+        b = 1.0 / math.sqrt(n_in)
+        w[name + ".weight"] = uni((n_out, n_in), b)
+        if bias:
+            w[name + ".bias"] = uni((n_out,), b)
+
+    def conv(name, c_out, c_in, k, transpose=False):
+        shape = (c_in, c_out, k, k) if transpose else (c_out, c_in, k, k)
+        std = math.sqrt(2.0 / (c_in * k * k + c_out * k * k))
+        w[name + ".weight"] = (rng.standard_normal(shape) * std).astype(np.float32)
+        w[name + ".bias"] = uni((c_out,), 0.05)
+
+    linear("decoder.fc_p", 32, 3)
+    for i in range(5):
+        linear(f"decoder.fc_c.{i}", 32, 32)
+    for i in range(5):
+        linear(f"decoder.blocks.{i}.fc_0", 32, 32)
+        linear(f"decoder.blocks.{i}.fc_1", 32, 32)
+    linear("decoder.fc_out", 1, 32)
+    linear("encoder.fc_pos", 64, 3)
+    for i in range(5):
+        linear(f"encoder.blocks.{i}.fc_0", 32, 64)
+        linear(f"encoder.blocks.{i}.fc_1", 32, 32)
+        linear(f"encoder.blocks.{i}.shortcut", 32, 64, bias=False)
+    linear("encoder.fc_c", 32, 32)
+    c_in = 32
+    for i, c_out in enumerate([32, 64, 128, 256]):
+        conv(f"encoder.unet.down_convs.{i}.conv1", c_out, c_in, 3)
+        conv(f"encoder.unet.down_convs.{i}.conv2", c_out, c_out, 3)
+        c_in = c_out
+    for i in range(3):
+        c_out = c_in // 2
+        conv(f"encoder.unet.up_convs.{i}.upconv", c_out, c_in, 2, transpose=True)
+        conv(f"encoder.unet.up_convs.{i}.conv1", c_out, 2 * c_out, 3)
+        conv(f"encoder.unet.up_convs.{i}.conv2", c_out, c_out, 3)
+        c_in = c_out
+    conv("encoder.unet.conv_final", 32, c_in, 1)
+    return w

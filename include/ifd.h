@@ -173,9 +173,12 @@ typedef struct ifd_opt_params {
  * written back - lets a caller resume or teacher-force single steps.
  * loss (optional) [B,2]: {sum_k BCE_k, repulsion_loss_b} evaluated at the last step's
  * pre-update points (what the reference prints at :229-236, before 1/B and weights).
+ * loss_batch_per_cloud (optional) [B] int32: overrides prm->loss_batch per cloud, so clouds that belong to
+ * different reference batches (the last batch of a file is shorter) can share one launch.
  * 6 <= K <= 1024. */
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
-                 const ifd_opt_params* prm, float* m, float* v, float* loss, void* stream);
+                 const ifd_opt_params* prm, const int32_t* loss_batch_per_cloud,
+                 float* m, float* v, float* loss, void* stream);
 
 /* Diagnostics (no reference counterpart): counters of the most recent ifd_optimize on this context, copied
  * to HOST memory; synchronises the device.  [0] wave-level neighbour-list rebuilds, [1] wave-level certificate

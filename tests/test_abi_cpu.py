@@ -83,7 +83,7 @@ def test_create_rejects_bad_arguments(lib):
     cfg.plane_resolution = 128
     assert not lib.ifd_create(w.ctypes.data, w.size, ctypes.byref(cfg), 0)
     assert b"only the shipped" in lib.ifd_last_error(None)
-    assert lib.ifd_optimize(None, None, None, 1, 1024, None, None, None, None, None) == -1
+    assert lib.ifd_optimize(None, None, None, 1, 1024, None, None, None, None, None, None) == -1
 
 
 def test_no_gpu_fails_loudly(np_weights):
