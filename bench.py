@@ -74,11 +74,13 @@ def synth_clouds(n, seed=1234):
     return out
 
 
-def cpu_baseline(clouds, n_sample=16, n_steps=50):
+def cpu_baseline(clouds, n_sample=16, budget_s=15.0):
     """The CPU oracle (a port of the reference's op sequence: bmm-kNN + topk, autograd, torch.optim.Adam) timed
-    on the host cores on a bounded sample, scaled to 501 steps.  Reported next to the GPU number, not a target."""
+    on the host cores on a bounded sample, scaled to 501 steps.  Reported next to the GPU number, not a target.
+    Threads are capped at 16: with one thread per core of a 256-core host the small ops of this loop run
+    ~100x slower (measured: 22 s per step), which would say nothing about the CPU path."""
     from oracle import convonet_oracle as O
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     w = O.to_torch(O.make_random_weights(0))
     x = torch.from_numpy(clouds[:n_sample])
@@ -92,7 +94,11 @@ def cpu_baseline(clouds, n_sample=16, n_steps=50):
     idx = np.stack([rng.integers(0, len(p), K_POINTS) for p in proc])
     init = O.init_points(proc, idx, rng.standard_normal((n_sample, K_POINTS, 3)).astype(np.float32))
     t_pre = time.perf_counter() - t0
-    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=0, normalize=False)       # warm
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=0, normalize=False)       # warm-up step
+    t0 = time.perf_counter()
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=1, normalize=False)       # 2-step probe
+    probe = (time.perf_counter() - t0) / 2
+    n_steps = int(max(3, min(50, budget_s / max(probe, 1e-3))))
     t0 = time.perf_counter()
     O.optimize_points(w, init, planes, rep_weight=500.0, iterations=n_steps - 1, normalize=True)
     t_opt = time.perf_counter() - t0
