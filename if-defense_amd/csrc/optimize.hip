@@ -139,10 +139,16 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
         const float* qp = planes + ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * q;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+#ifdef IFD_EXP_NOGATHER   // experiment: no plane reads (isolates the MLP chain)
+            tap[P][0][mt] = f32x4{x0, x1, x2, x0}; tap[P][1][mt] = f32x4{x1, x1, x2, x0};
+            tap[P][2][mt] = f32x4{x2, x1, x2, x0}; tap[P][3][mt] = f32x4{x0, x0, x2, x0};
+            (void)qp;
+#else
             tap[P][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
             tap[P][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
             tap[P][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
             tap[P][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+#endif
         }
     }
     // ---- forward: c = sum over planes of the bilinear sample -------------------------------------

@@ -332,3 +332,45 @@ def test_unet_matches_reference_and_is_batch_invariant(restorer, golden):
     assert _rel(got, golden["planes01"][0, 0]) < 2e-5
     big = restorer.unet(torch.cat([torch.randn(2, 3, 64, 64, 32), pre, torch.randn(3, 3, 64, 64, 32)]))
     assert torch.equal(big[2], out[0])                                          # fixed summation order: batch-size independent
+
+
+def test_cli_end_to_end(tmp_path, np_weights):
+    """python -m ifdefense_amd.opt_defense on a 3-key .npz: same output location / keys / dtypes as the reference."""
+    import subprocess, sys, os
+    wpath = tmp_path / "convonet.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in np_weights.items()}, wpath)
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "convonet_golden.npz")))
+    src = tmp_path / "kNN-pointnet.npz"
+    pc6 = np.concatenate([g["raw"], np.zeros_like(g["raw"])], axis=-1)            # [N,K,6]: normals are sliced off
+    np.savez(src, test_pc=pc6, test_label=np.array([0, 8, 30, 39]), target_label=np.array([1, 2, 3, 4]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "ifdefense_amd.opt_defense", "--data_root", str(src), "--iterations=20",
+                        "--weights", str(wpath), "--seed=5"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = tmp_path / "ConvONet-Opt" / "convonet_opt-kNN-pointnet.npz"
+    z = np.load(out)
+    assert sorted(z.files) == ["target_label", "test_label", "test_pc"]
+    assert z["test_pc"].shape == (4, 1024, 3) and z["test_pc"].dtype == np.float32
+    assert z["test_label"].dtype == np.uint8 and z["test_label"].tolist() == [0, 8, 30, 39]
+    np.testing.assert_allclose(np.linalg.norm(z["test_pc"], axis=-1).max(axis=1), 1.0, rtol=1e-6)
+
+
+def test_full_size_properties(restorer):
+    """BASELINE size (2468 clouds x 1024 points x 501 steps): size-independent properties."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import ifdefense_amd as I
+    clouds = bench.synth_clouds(2468)
+    args = I.DefenseArgs(iterations=500, seed=1234)
+    full = I.defend_point_cloud(restorer, clouds, args)
+    assert full.shape == (2468, 1024, 3) and np.isfinite(full).all()
+    np.testing.assert_allclose(np.linalg.norm(full, axis=-1).max(axis=1), 1.0, rtol=1e-5)       # unit sphere
+    assert np.abs(full.mean(axis=1)).max() < 1e-4                                               # centred
+    c = restorer.counters()
+    print("2468 clouds x 501 steps: %.1f synchronous list rebuilds per cloud, %d certificate failures, %.2f passes/rebuild"
+          % (c["knn_rebuilds"] / 8 / 2468, c["knn_brute_scans"], c["knn_passes"] / max(1, c["knn_rebuilds"])))
+    # sharding invariance at full size: two halves, concatenated, bit-identical
+    lo = I.defend_point_cloud(restorer, clouds[:1234], args, cloud_index_base=0, total_clouds=2468)
+    hi = I.defend_point_cloud(restorer, clouds[1234:], args, cloud_index_base=1234, total_clouds=2468)
+    assert np.array_equal(np.concatenate([lo, hi]), full)
