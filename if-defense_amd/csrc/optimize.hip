@@ -26,6 +26,8 @@
 #include "ifd_device.h"
 #include "ifd_internal.h"
 
+#include <cstdlib>
+
 namespace ifd {
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -108,7 +110,9 @@ enum { MODE_OPT = 0, MODE_SUM = 1 };
 
 // One 16-point tile on one wave.  The 4 lanes (n, q = 0..3) share point n and hold 8 of its 32 channels each.
 // Returns logit, the BCE term and d(loss)/dx (valid on every lane after the quad reduce).
-template <int MODE, bool WANT_GRAD>
+// HOLD = true : all 24 tap loads in one batch, kept in 96 VGPRs for the backward (needs ~256 VGPRs: 2 waves/SIMD)
+// HOLD = false: one plane at a time, re-gathered for the backward (fits 168 VGPRs: 3 waves/SIMD)
+template <int MODE, bool WANT_GRAD, bool HOLD>
 __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const float* __restrict__ planes,
                                              float x0, float x1, float x2, int lane, const DecConst dc,
                                              float thr, float inv_lb, float& logit_out, float& bce_out,
@@ -131,44 +135,51 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
     }
     constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
 
-    // ---- gather: all 12 taps x 8 channels of this lane in ONE batch of 24 loads, kept for the backward ---
-    f32x4 tap[3][4][2];        // [plane][nw, ne, sw, se][M-tile]  = 96 VGPRs
-#pragma unroll
-    for (int P = 0; P < 3; ++P) {
-        const int a0 = AX0[P], a1 = AX1[P];
-        const float* qp = planes + ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * q;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#ifdef IFD_EXP_NOGATHER   // experiment: no plane reads (isolates the MLP chain)
-            tap[P][0][mt] = f32x4{x0, x1, x2, x0}; tap[P][1][mt] = f32x4{x1, x1, x2, x0};
-            tap[P][2][mt] = f32x4{x2, x1, x2, x0}; tap[P][3][mt] = f32x4{x0, x0, x2, x0};
-            (void)qp;
-#else
-            tap[P][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
-            tap[P][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
-            tap[P][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
-            tap[P][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
-#endif
-        }
-    }
-    // ---- forward: c = sum over planes of the bilinear sample -------------------------------------
+    // ---- gather + forward: c = sum over planes of the bilinear sample --------------------------------
+    f32x4 tap[HOLD ? 3 : 1][4][2];        // [plane][nw, ne, sw, se][M-tile]  (96 VGPRs when held)
     f32x8 c;
 #pragma unroll
     for (int r = 0; r < 8; ++r) c[r] = 0.f;
+    if (HOLD) {
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            const int a0 = AX0[P], a1 = AX1[P];
+            const float* qp = planes + ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[HOLD ? P : 0][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[HOLD ? P : 0][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[HOLD ? P : 0][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[HOLD ? P : 0][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
+    }
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
         const int a0 = AX0[P], a1 = AX1[P];
+        const int tp = HOLD ? P : 0;
+        if (!HOLD) {
+            const float* qp = planes + ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[tp][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[tp][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[tp][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[tp][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
         const float wnw = w0[a0] * w0[a1], wne = w1[a0] * w0[a1], wsw = w0[a0] * w1[a1], wse = w1[a0] * w1[a1];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s = tap[P][0][mt][j] * wnw;
-                s = fmaf(tap[P][1][mt][j], wne, s);
-                s = fmaf(tap[P][2][mt][j], wsw, s);
-                s = fmaf(tap[P][3][mt][j], wse, s);
+                float s = tap[tp][0][mt][j] * wnw;
+                s = fmaf(tap[tp][1][mt][j], wne, s);
+                s = fmaf(tap[tp][2][mt][j], wsw, s);
+                s = fmaf(tap[tp][3][mt][j], wse, s);
                 c[4 * mt + j] += s;
             }
+        if (!HOLD) __builtin_amdgcn_sched_barrier(0);   // one plane's 8 tap loads in flight at a time
     }
 
     // ---- forward MLP ------------------------------------------------------------------------------
@@ -260,20 +271,36 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
         const int a0 = AX0[P], a1 = AX1[P];
+        const int tp = HOLD ? P : 0;
+        if (!HOLD) {
+            int off = ((P * RES + cell[a1]) * RES + cell[a0]) * CH + 4 * q;
+            // opaque to the optimiser: otherwise these loads are CSE'd with the forward gather and the taps are
+            // kept live (and spilled) across the whole MLP.  The re-read is L1/L2 traffic.
+            asm volatile("" : "+v"(off));
+            const float* qp = planes + off;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[tp][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[tp][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[tp][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[tp][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
         float dnw = 0.f, dne = 0.f, dsw = 0.f, dse = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float d = dcf[4 * mt + j];
-                dnw = fmaf(tap[P][0][mt][j], d, dnw); dne = fmaf(tap[P][1][mt][j], d, dne);
-                dsw = fmaf(tap[P][2][mt][j], d, dsw); dse = fmaf(tap[P][3][mt][j], d, dse);
+                dnw = fmaf(tap[tp][0][mt][j], d, dnw); dne = fmaf(tap[tp][1][mt][j], d, dne);
+                dsw = fmaf(tap[tp][2][mt][j], d, dsw); dse = fmaf(tap[tp][3][mt][j], d, dse);
             }
         const float gix = (dne - dnw) * w0[a1] + (dse - dsw) * w1[a1];
         const float giy = (dsw - dnw) * w0[a0] + (dse - dne) * w1[a0];
         const float sc = (0.5f * (float)(RES - 1)) * 2.f;
         g[a0] += live[a0] * ((gix * sc) / dc.sdiv);
         g[a1] += live[a1] * ((giy * sc) / dc.sdiv);
+        if (!HOLD) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -282,6 +309,289 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
         v += __shfl_xor(v, 32);
         dx[a] = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two 16-point sub-tiles per wave, processed in lock-step (the optimiser's phase A).
+//   * 4 independent accumulator chains per layer (2 sub-tiles x 2 M-tiles): no dependent-MFMA stalls, and the
+//     VALU epilogue of one sub-tile (bias, ReLU, mask) overlaps the other sub-tile's MFMAs;
+//   * every A operand (weight) is fetched from LDS once and feeds both sub-tiles: half the LDS reads per MFMA;
+//   * ReLU masks are packed 8 bits per layer and made opaque (asm) so the compiler keeps them as 1 VGPR each.
+// The taps are gathered one plane at a time and re-gathered for the backward pass (L1/L2 hits): holding them
+// for two sub-tiles would need 192 VGPRs.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mask_pos_packed(const f32x8& v) {
+    uint32_t b[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) b[r] = v[r] > 0.f ? (1u << r) : 0u;
+    uint32_t m = ((b[0] | b[1]) | (b[2] | b[3])) | ((b[4] | b[5]) | (b[6] | b[7]));
+    asm volatile("" : "+v"(m));      // keep it a bit-mask: otherwise hipcc re-expands it into 8 float selectors
+    return m;
+}
+
+struct SubGeo {                      // per-point sampling geometry of one sub-tile lane
+    float x[3], w0[3], w1[3], live[3];
+    int cell[3];
+};
+
+__device__ __forceinline__ void sub_geometry(SubGeo& g, float x0, float x1, float x2, const DecConst& dc) {
+    g.x[0] = x0; g.x[1] = x1; g.x[2] = x2;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float pix;
+        pixel_coord(g.x[a], dc, pix, g.live[a]);
+        const int ci = min((int)floorf(pix), RES - 2);
+        g.cell[a] = ci;
+        g.w1[a] = pix - (float)ci;
+        g.w0[a] = ((float)ci + 1.f) - pix;
+    }
+}
+
+// two sub-tiles, shared A operands: 32 MFMAs per layer, 16 LDS reads
+template <bool TRANSPOSED>
+__device__ __forceinline__ void dense32x2(const float* __restrict__ wl, const LaneOff& lo, const f32x8& in0,
+                                          const f32x8& in1, Acc2& acc0, Acc2& acc1) {
+    const float* base = wl + (TRANSPOSED ? lo.bwd : lo.fwd);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int mtp = s >> 2, rp = s & 3;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + 16 * mt) : (16 * mt * W_STRIDE + 16 * mtp + 4 * rp);
+            const float a = base[off];
+            acc0.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in0[s], acc0.t[mt], 0, 0, 0);
+            acc1.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in1[s], acc1.t[mt], 0, 0, 0);
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void decoder_tile2(const float* __restrict__ W, const float* __restrict__ planes,
+                                              const f32x4 xa, const f32x4 xb, int lane, const DecConst dc, float thr,
+                                              float inv_lb, float (&bce)[2], float (&dx)[2][3]) {
+    const int n = lane & 15, q = lane >> 4;
+    LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
+    asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
+    constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
+    SubGeo geo[2];
+    sub_geometry(geo[0], xa.x, xa.y, xa.z, dc);
+    sub_geometry(geo[1], xb.x, xb.y, xb.z, dc);
+
+    // ---- gather + forward bilinear sample, one plane (2 x 8 loads) at a time ---------------------------------
+    f32x8 c[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
+#pragma unroll
+    for (int P = 0; P < 3; ++P) {
+        const int a0 = AX0[P], a1 = AX1[P];
+        f32x4 tap[2][4][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* qp = planes + ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SubGeo& g = geo[t];
+            const float wnw = g.w0[a0] * g.w0[a1], wne = g.w1[a0] * g.w0[a1], wsw = g.w0[a0] * g.w1[a1],
+                        wse = g.w1[a0] * g.w1[a1];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = tap[t][0][mt][j] * wnw;
+                    s = fmaf(tap[t][1][mt][j], wne, s);
+                    s = fmaf(tap[t][2][mt][j], wsw, s);
+                    s = fmaf(tap[t][3][mt][j], wse, s);
+                    c[t][4 * mt + j] += s;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- forward MLP ----------------------------------------------------------------------------------------
+    Acc2 net[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                net[t].t[mt][j] = fmaf(wp.z, geo[t].x[2], fmaf(wp.y, geo[t].x[1], fmaf(wp.x, geo[t].x[0], wp.w)));
+        }
+    uint32_t mask_a[2][NBLK], mask_h[2][NBLK];
+    const float* Wd = W + DEC_OFF_W;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const float* Wl = Wd + 3 * i * W_LAYER;
+        Acc2 a[2], h[2], o[2];
+        {
+            const Acc2 b = load_bias(W, 3 * i, lo);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { a[t].t[0] = b.t[0] + net[t].t[0]; a[t].t[1] = b.t[1] + net[t].t[1]; }
+        }
+        dense32x2<false>(Wl, lo, c[0], c[1], a[0], a[1]);                       // a_i = n_i + fc_c[i](c)
+        f32x8 ra[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x8 af = flat(a[t]);
+            mask_a[t][i] = mask_pos_packed(af);
+            ra[t] = relu8(af);
+        }
+        {
+            const Acc2 b = load_bias(W, 3 * i + 1, lo);
+            h[0] = b; h[1] = b;
+        }
+        dense32x2<false>(Wl + W_LAYER, lo, ra[0], ra[1], h[0], h[1]);          // fc_0(relu(a))
+        f32x8 rh[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x8 hf = flat(h[t]);
+            mask_h[t][i] = mask_pos_packed(hf);
+            rh[t] = relu8(hf);
+        }
+        {
+            const Acc2 b = load_bias(W, 3 * i + 2, lo);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { o[t].t[0] = b.t[0] + a[t].t[0]; o[t].t[1] = b.t[1] + a[t].t[1]; }
+        }
+        dense32x2<false>(Wl + 2 * W_LAYER, lo, rh[0], rh[1], o[0], o[1]);      // a + fc_1(relu(h))
+        net[0] = o[0];
+        net[1] = o[1];
+        __builtin_amdgcn_sched_barrier(0);      // one block at a time: bounds the weight-load hoisting
+    }
+    f32x8 wout;
+    {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + lo.q4);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
+    }
+    f32x8 dn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x8 nf = flat(net[t]);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part = fmaf(wout[r], fmaxf(nf[r], 0.f), part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float logit = part + W[DEC_OFF_BOUT];
+        float dl;
+        if (MODE == MODE_OPT) {
+            const float e = expf(-fabsf(logit));
+            bce[t] = fmaxf(logit, 0.f) - thr * logit + log1pf(e);
+            const float sig = logit >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            dl = (sig - thr) * inv_lb;
+        } else {
+            bce[t] = logit;                   // MODE_SUM: report the logit, gradient of sum(logits)
+            dl = 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dn[t][r] = nf[r] > 0.f ? dl * wout[r] : 0.f;
+    }
+
+    // ---- backward (parameters frozen: only the path to the input) -----------------------------------------------
+    Acc2 dcc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { dcc[t].t[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dcc[t].t[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int i = NBLK - 1; i >= 0; --i) {
+        const float* Wl = Wd + 3 * i * W_LAYER;
+        Acc2 z[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { z[t].t[0] = f32x4{0.f, 0.f, 0.f, 0.f}; z[t].t[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        dense32x2<true>(Wl + 2 * W_LAYER, lo, dn[0], dn[1], z[0], z[1]);       // fc_1^T dn
+        f32x8 dh[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            dh[t] = flat(z[t]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dh[t][r] = ((mask_h[t][i] >> r) & 1u) ? dh[t][r] : 0.f;
+            z[t].t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            z[t].t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        dense32x2<true>(Wl + W_LAYER, lo, dh[0], dh[1], z[0], z[1]);           // fc_0^T dh
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x8 tt = flat(z[t]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dn[t][r] += ((mask_a[t][i] >> r) & 1u) ? tt[r] : 0.f;   // delta a_i
+        }
+        dense32x2<true>(Wl, lo, dn[0], dn[1], dcc[0], dcc[1]);                 // dc += fc_c^T da
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float g[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float d = dn[t][4 * mt + j];
+                g[t][0] = fmaf(wp.x, d, g[t][0]); g[t][1] = fmaf(wp.y, d, g[t][1]); g[t][2] = fmaf(wp.z, d, g[t][2]);
+            }
+        }
+    // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
+    f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
+#pragma unroll
+    for (int P = 0; P < 3; ++P) {
+        const int a0 = AX0[P], a1 = AX1[P];
+        f32x4 tap[2][4][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int off = ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
+            asm volatile("" : "+v"(off));      // opaque: do not CSE with (and keep alive since) the forward gather
+            const float* qp = planes + off;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SubGeo& gg = geo[t];
+            float dnw = 0.f, dne = 0.f, dsw = 0.f, dse = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = dcf[t][4 * mt + j];
+                    dnw = fmaf(tap[t][0][mt][j], d, dnw); dne = fmaf(tap[t][1][mt][j], d, dne);
+                    dsw = fmaf(tap[t][2][mt][j], d, dsw); dse = fmaf(tap[t][3][mt][j], d, dse);
+                }
+            const float gix = (dne - dnw) * gg.w0[a1] + (dse - dsw) * gg.w1[a1];
+            const float giy = (dsw - dnw) * gg.w0[a0] + (dse - dne) * gg.w1[a0];
+            const float sc = (0.5f * (float)(RES - 1)) * 2.f;
+            g[t][a0] += gg.live[a0] * ((gix * sc) / dc.sdiv);
+            g[t][a1] += gg.live[a1] * ((giy * sc) / dc.sdiv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = g[t][a];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            dx[t][a] = v;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,7 +812,8 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
 // ---------------------------------------------------------------------------------------------
 // block helpers
 // ---------------------------------------------------------------------------------------------
-constexpr int NWAVES = OPT_THREADS / 64;
+constexpr int OWN_WAVES = OPT_THREADS / 64;   // waves whose threads own points (kNN / Adam duty): threads [0, 512)
+constexpr int MAX_WAVES = 16;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -562,7 +873,10 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
 // ---------------------------------------------------------------------------------------------
 // the persistent per-cloud optimiser
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
+// NW waves per workgroup (8: 2 per SIMD / 256 VGPRs, 12: 3 per SIMD / 168 VGPRs); threads [0,512) own two points
+// each (kNN + Adam duty), every wave pulls 16-point decoder tiles from an LDS counter.
+template <int NW, bool HOLD>
+__global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
     float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
     const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
@@ -573,15 +887,17 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
     f32x4* G = X + MAXK;                                             // occupancy gradient (+ BCE term in .w)
     long long* F = reinterpret_cast<long long*>(G + MAXK);           // fixed-point neighbour-gradient scatter
     uint16_t* L = reinterpret_cast<uint16_t*>(F + 3 * MAXK);         // list staging [MAXK][STAGE_M] (rebuilds)
-    float* scratch = reinterpret_cast<float*>(L + MAXK * STAGE_M);   // 96 floats
+    float* scratch = reinterpret_cast<float*>(L + MAXK * STAGE_M);   // 128 floats
 
     const int cloud = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pl = planes + (A.shared_planes ? (size_t)0 : (size_t)cloud * CLOUD_PLANE_FLOATS);
     float* pc = p + (size_t)cloud * K * 3;
-    const int pa = tid, pb = tid + OPT_THREADS;                      // the two points this thread owns
-    const int ntiles = (K + 15) >> 4;
+    const bool owner = tid < OPT_THREADS;
+    const int pa = owner ? tid : MAXK, pb = owner ? tid + OPT_THREADS : MAXK;   // the two points this thread owns
+    const int ntiles = HOLD ? (K + 15) >> 4 : (K + 31) >> 5;          // HOLD: 16-point tiles, else 32-point super-tiles
 
+    const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
     float mm[6], vv[6];
 #pragma unroll
@@ -600,7 +916,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
             }
         }
     }
-    for (int i = tid; i < MAXK * 3; i += OPT_THREADS) F[i] = 0;
+    for (int i = tid; i < MAXK * 3; i += NW * 64) F[i] = 0;
 
     const DecConst dc = A.dc;
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
@@ -611,38 +927,32 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
     double b1t = pow(0.9, (double)A.t0), b2t = pow(0.999, (double)A.t0);
     float rep_loss_a = 0.f, rep_loss_b = 0.f;
     // certified neighbour lists of the two owned points
-    uint16_t* La = knn_lists + ((size_t)cloud * MAXK + pa) * LIST_M;        // global (L2-resident)
-    uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + pb) * LIST_M;
-    uint16_t* Sa = L + pa * STAGE_M;                                         // LDS staging slots (rebuilds)
-    uint16_t* Sb = L + pb * STAGE_M;
+    uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;   // global (L2-resident)
+    uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + (pb & (MAXK - 1))) * LIST_M;
+    uint16_t* Sa = L + (pa & (MAXK - 1)) * STAGE_M;                          // LDS staging slots (rebuilds)
+    uint16_t* Sb = L + (pb & (MAXK - 1)) * STAGE_M;
     KnnPt ka = {-1, 0.f, 0.16f * LIST_M, f32x4{0.f, 0.f, 0.f, 0.f}};         // al: ~80 % fill on a flat patch
     KnnPt kb = ka;
-    float* dmaxbuf = scratch + 32;                                   // [2][NWAVES] per-wave max |x - x0| (next step)
-    float* movebuf = scratch + 64;                                   // [2][NWAVES] per-wave max single-step move
+    float* dmaxbuf = scratch + 32;                                   // [2][MAX_WAVES] per-wave max |x - x0| (next step)
+    float* movebuf = scratch + 64;                                   // [2][MAX_WAVES] per-wave max single-step move
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
+    int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
     unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0;
     if (tid < 2) rebuild_flag[tid] = 0;
-    if (tid < 2 * NWAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
+    if (tid == 0) *tile_ctr = 0;
+    if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
     __syncthreads();
 
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
         float gca[3] = {0.f, 0.f, 0.f}, gcb[3] = {0.f, 0.f, 0.f};
-        // waves 0-3 (one per SIMD) run decoder then kNN, waves 4-7 the other way round.
+        // Work of one step: ntiles decoder tiles (pulled from an LDS counter by every wave) + the kNN/repulsion of
+        // the 8 owner waves.  Waves 4-7 do their kNN first, waves 0-3 after a few tiles, so that each SIMD always
+        // has MFMA work queued next to the VALU-only kNN; waves >= 8 (3-per-SIMD configuration) only pull tiles.
+        const int quota = wave < 4 ? (ntiles + 2 * NW - 1) / (2 * NW) : 0;
 #pragma unroll 1
         for (int phase = 0; phase < 2; ++phase) {
-            const bool do_dec = (phase == 0) == (wave < NWAVES / 2);
-            if (do_dec) {
-#pragma unroll 1
-                for (int tile = wave; tile < ntiles; tile += NWAVES) {
-                    const int tp = min(tile * 16 + (lane & 15), K - 1);
-                    const f32x4 x = X[tp];
-                    float logit, bce, dx[3];
-                    decoder_tile<MODE_OPT, true>(W, pl, x.x, x.y, x.z, lane, dc, A.threshold, inv_lb, logit,
-                                                 bce, dx);
-                    if (lane < 16 && tile * 16 + lane < K) G[tp] = f32x4{dx[0], dx[1], dx[2], bce};
-                }
-            } else if (use_rep) {
+            if (phase == 1 && wave < OWN_WAVES && use_rep) {
                 Top5 ta, tb;
                 top5_init(ta);
                 top5_init(tb);
@@ -653,9 +963,9 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
                     const bool force = step == 0 || rebuild_flag[step & 1] != 0;      // block-uniform
                     float dmax = 0.f, mv = 0.f;
 #pragma unroll
-                    for (int w = 0; w < NWAVES; ++w) {
-                        dmax = fmaxf(dmax, dmaxbuf[(step & 1) * NWAVES + w]);
-                        mv = fmaxf(mv, movebuf[(step & 1) * NWAVES + w]);
+                    for (int w = 0; w < OWN_WAVES; ++w) {
+                        dmax = fmaxf(dmax, dmaxbuf[(step & 1) * MAX_WAVES + w]);
+                        mv = fmaxf(mv, movebuf[(step & 1) * MAX_WAVES + w]);
                     }
                     // the certificate must survive one more step: r5 grows <= 2 mv, both displacements <= mv
                     const float soft_slack = 6.f * mv;
@@ -691,6 +1001,30 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
                 if (pa < K) rep_point(X, F, pa, ta, rc, rep_loss_a, gca, true);
                 if (pb < K) rep_point(X, F, pb, tb, rc, rep_loss_b, gcb, true);
             }
+            // decoder tiles: phase 0 = up to `quota` tiles before the kNN, phase 1 = until the step's tiles run out
+#pragma unroll 1
+            for (int n = 0; phase == 1 || n < quota; ++n) {
+                int tile = 0;
+                if (lane == 0) tile = atomicAdd(tile_ctr, 1);
+                tile = __shfl(tile, 0);
+                if (tile >= ntiles) break;
+                if (HOLD) {          // one 16-point tile, taps held in registers
+                    const int tp = min(tile * 16 + (lane & 15), K - 1);
+                    const f32x4 x = X[tp];
+                    float logit, bce, dx[3];
+                    decoder_tile<MODE_OPT, true, true>(W, pl, x.x, x.y, x.z, lane, dc, A.threshold, inv_lb, logit, bce, dx);
+                    if (lane < 16 && tile * 16 + lane < K) G[tp] = f32x4{dx[0], dx[1], dx[2], bce};
+                } else {             // two 16-point sub-tiles in lock-step
+                    const int ia = tile * 32 + (lane & 15), ib = ia + 16;
+                    const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
+                    float bce[2], dx[2][3];
+                    decoder_tile2<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
+                    if (lane < 16) {
+                        if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
+                        if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
+                    }
+                }
+            }
         }
         __syncthreads();
         if (last && loss_out != nullptr) {   // losses at the pre-update points of the last step
@@ -698,11 +1032,11 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
             float rep = (pa < K ? rep_loss_a : 0.f) + (pb < K ? rep_loss_b : 0.f);
             occ = wave_sum(occ);
             rep = wave_sum(rep);
-            if (lane == 0) { scratch[wave] = occ; scratch[NWAVES + wave] = rep; }
+            if (lane == 0) { scratch[wave] = occ; scratch[MAX_WAVES + wave] = rep; }
             __syncthreads();
             if (tid == 0) {
                 float so = 0.f, sr = 0.f;
-                for (int w = 0; w < NWAVES; ++w) { so += scratch[w]; sr += scratch[NWAVES + w]; }
+                for (int w = 0; w < NW; ++w) { so += scratch[w]; sr += scratch[MAX_WAVES + w]; }
                 loss_out[2 * cloud + 0] = so;
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
@@ -749,10 +1083,10 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
         dmax2 = wave_max(dmax2);
         mv2 = wave_max(mv2);
         if (lane == 0) {
-            dmaxbuf[((step + 1) & 1) * NWAVES + wave] = sqrtf(dmax2) * 1.00001f + 1e-7f;
-            movebuf[((step + 1) & 1) * NWAVES + wave] = sqrtf(mv2);
+            dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(dmax2) * 1.00001f + 1e-7f;
+            movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
         }
-        if (tid == 0) rebuild_flag[step & 1] = 0;      // consumed by every wave before the mid-step barrier
+        if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
         __syncthreads();
     }
 
@@ -760,6 +1094,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void optimize_kernel(
         atomicAdd(counters + 0, (unsigned long long)n_rebuild);   // wave-level list rebuilds
         atomicAdd(counters + 1, (unsigned long long)n_brute);     // wave-level certificate failures (exact scans)
         atomicAdd(counters + 2, (unsigned long long)n_pass);      // wave-level candidate-collection passes
+        if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
 #pragma unroll
@@ -795,14 +1130,14 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void decode_kernel(const float* __r
     const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
     const float* pc = p + (size_t)cloud * K * 3;
     const int ntiles = (K + 15) >> 4;
-    for (int tile = wave; tile < ntiles; tile += NWAVES) {
+    for (int tile = wave; tile < ntiles; tile += (int)(blockDim.x >> 6)) {
         const int tp = min(tile * 16 + (lane & 15), K - 1);
         const float x0 = pc[3 * tp], x1 = pc[3 * tp + 1], x2 = pc[3 * tp + 2];
         float logit, bce, dx[3] = {0.f, 0.f, 0.f};
         if (dlogit_dp != nullptr)
-            decoder_tile<MODE_SUM, true>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
+            decoder_tile<MODE_SUM, true, true>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
         else
-            decoder_tile<MODE_SUM, false>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
+            decoder_tile<MODE_SUM, false, true>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
         if (lane < 16 && tile * 16 + lane < K) {
             logits[(size_t)cloud * K + tp] = logit;
             if (dlogit_dp != nullptr) {
@@ -877,7 +1212,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + MAXK * 3 * 8 + MAXK * STAGE_M * 2 + 96 * 4;   // 158,352 B
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + MAXK * 3 * 8 + MAXK * STAGE_M * 2 + 128 * 4;   // 158,480 B
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;
 constexpr size_t NRM_LDS = MAXK * 16 + 64;
@@ -886,8 +1221,11 @@ static_assert(OPT_LDS <= 160 * 1024, "LDS budget");
 size_t knn_list_bytes(int B) { return (size_t)B * MAXK * LIST_M * sizeof(uint16_t); }
 
 hipError_t configure_optimize_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
@@ -897,14 +1235,25 @@ hipError_t configure_optimize_kernels() {
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
                            float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
                            unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(optimize_kernel, dim3(B), dim3(OPT_THREADS), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                       loss_batch_per_cloud, knn_lists, counters, K, a);
+    if (a.variant == 1)
+        hipLaunchKernelGGL((optimize_kernel<8, false>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
+                           loss_batch_per_cloud, knn_lists, counters, K, a);
+    else
+        hipLaunchKernelGGL((optimize_kernel<8, true>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
+                           loss_batch_per_cloud, knn_lists, counters, K, a);
     return hipGetLastError();
 }
 
 hipError_t launch_decode(const float* dec_img, const float* planes, const float* p, int B, int K,
                          float* logits, float* dlogit_dp, DecConst dc, hipStream_t s) {
-    hipLaunchKernelGGL(decode_kernel, dim3(B), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K, logits,
+    int threads = OPT_THREADS;
+    if (const char* e = getenv("IFD_DEC_THREADS")) threads = atoi(e);      // experiment hook: waves per workgroup
+    size_t lds = DEC_LDS;
+    if (const char* e = getenv("IFD_DEC_LDS")) {                           // experiment hook: force 1 workgroup / CU
+        lds = (size_t)atoi(e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(decode_kernel, dim3(B), dim3(threads), lds, s, dec_img, planes, p, K, logits,
                        dlogit_dp, dc);
     return hipGetLastError();
 }
