@@ -377,7 +377,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
     a.knn_scan_every_step = prm->knn_scan_every_step;
     { const char* d = getenv("IFD_SHARED_PLANES"); a.shared_planes = d ? atoi(d) : 0; }
-    { const char* d = getenv("IFD_OPT_VARIANT"); a.variant = d ? atoi(d) : 1; }
+    { const char* d = getenv("IFD_OPT_VARIANT"); a.variant = d ? atoi(d) : 2; }
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;

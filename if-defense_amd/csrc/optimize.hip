@@ -26,8 +26,6 @@
 #include "ifd_device.h"
 #include "ifd_internal.h"
 
-#include <cstdlib>
-
 namespace ifd {
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -110,9 +108,11 @@ enum { MODE_OPT = 0, MODE_SUM = 1 };
 
 // One 16-point tile on one wave.  The 4 lanes (n, q = 0..3) share point n and hold 8 of its 32 channels each.
 // Returns logit, the BCE term and d(loss)/dx (valid on every lane after the quad reduce).
-// HOLD = true : all 24 tap loads in one batch, kept in 96 VGPRs for the backward (needs ~256 VGPRs: 2 waves/SIMD)
-// HOLD = false: one plane at a time, re-gathered for the backward (fits 168 VGPRs: 3 waves/SIMD)
-template <int MODE, bool WANT_GRAD, bool HOLD>
+// TAPMODE 0: taps gathered one plane at a time and re-gathered for the backward pass
+//         1: all 24 tap loads in one batch, kept in 96 VGPRs for the backward (needs ~256 VGPRs: 2 waves/SIMD)
+//         2: all 24 tap loads in one batch, reduced at once to c (8) and the Jacobian d c / d x (24 VGPRs); the
+//            backward pass is J^T dc - no memory access, no taps held
+template <int MODE, bool WANT_GRAD, int TAPMODE>
 __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const float* __restrict__ planes,
                                              float x0, float x1, float x2, int lane, const DecConst dc,
                                              float thr, float inv_lb, float& logit_out, float& bce_out,
@@ -136,10 +136,18 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
     constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
 
     // ---- gather + forward: c = sum over planes of the bilinear sample --------------------------------
-    f32x4 tap[HOLD ? 3 : 1][4][2];        // [plane][nw, ne, sw, se][M-tile]  (96 VGPRs when held)
-    f32x8 c;
+    constexpr bool HOLD = TAPMODE != 0;       // batch all 24 loads
+    constexpr bool JAC = TAPMODE == 2;
+    f32x4 tap[HOLD ? 3 : 1][4][2];            // [plane][nw, ne, sw, se][M-tile]
+    f32x8 c, J[JAC ? 3 : 1];
 #pragma unroll
     for (int r = 0; r < 8; ++r) c[r] = 0.f;
+    if (JAC) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) J[JAC ? a : 0][r] = 0.f;
+    }
     if (HOLD) {
 #pragma unroll
         for (int P = 0; P < 3; ++P) {
@@ -154,6 +162,7 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
             }
         }
     }
+    const float jsc = ((0.5f * (float)(RES - 1)) * 2.f) / dc.sdiv;
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
         const int a0 = AX0[P], a1 = AX1[P];
@@ -169,18 +178,27 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
             }
         }
         const float wnw = w0[a0] * w0[a1], wne = w1[a0] * w0[a1], wsw = w0[a0] * w1[a1], wse = w1[a0] * w1[a1];
+        const float s0 = live[a0] * jsc, s1 = live[a1] * jsc;
+        const float k0n = s0 * w0[a1], k0s = s0 * w1[a1];       // d/du0: (ne - nw) w0[a1] + (se - sw) w1[a1]
+        const float k1w = s1 * w0[a0], k1e = s1 * w1[a0];       // d/du1: (sw - nw) w0[a0] + (se - ne) w1[a0]
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s = tap[tp][0][mt][j] * wnw;
-                s = fmaf(tap[tp][1][mt][j], wne, s);
-                s = fmaf(tap[tp][2][mt][j], wsw, s);
-                s = fmaf(tap[tp][3][mt][j], wse, s);
+                const float nw = tap[tp][0][mt][j], ne = tap[tp][1][mt][j], sw = tap[tp][2][mt][j], se = tap[tp][3][mt][j];
+                float s = nw * wnw;
+                s = fmaf(ne, wne, s);
+                s = fmaf(sw, wsw, s);
+                s = fmaf(se, wse, s);
                 c[4 * mt + j] += s;
+                if (JAC) {
+                    J[JAC ? a0 : 0][4 * mt + j] += fmaf(se - sw, k0s, (ne - nw) * k0n);
+                    J[JAC ? a1 : 0][4 * mt + j] += fmaf(se - ne, k1e, (sw - nw) * k1w);
+                }
             }
         if (!HOLD) __builtin_amdgcn_sched_barrier(0);   // one plane's 8 tap loads in flight at a time
     }
+    if (JAC) __builtin_amdgcn_sched_barrier(0);          // the taps die here
 
     // ---- forward MLP ------------------------------------------------------------------------------
     Acc2 net;
@@ -267,9 +285,18 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
             const float d = dn[4 * mt + j];
             g[0] = fmaf(wp.x, d, g[0]); g[1] = fmaf(wp.y, d, g[1]); g[2] = fmaf(wp.z, d, g[2]);
         }
+    if (JAC) {     // d loss / d x through the sampled features: J^T dc (no memory access)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float acc = g[a];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc = fmaf(J[JAC ? a : 0][r], dcf[r], acc);
+            g[a] = acc;
+        }
+    }
     // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid)
 #pragma unroll
-    for (int P = 0; P < 3; ++P) {
+    for (int P = 0; P < (JAC ? 0 : 3); ++P) {
         const int a0 = AX0[P], a1 = AX1[P];
         const int tp = HOLD ? P : 0;
         if (!HOLD) {
@@ -595,6 +622,324 @@ __device__ __forceinline__ void decoder_tile2(const float* __restrict__ W, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Software-pipelined version of the two-sub-tile schedule (SCHED = 2).
+//   region k.1 :  16 MFMAs of sub-tile 0, layer k   ||  VALU epilogue (bias/ReLU/mask) of sub-tile 1, layer k-1
+//   region k.2 :  16 MFMAs of sub-tile 1, layer k   ||  VALU epilogue of sub-tile 0, layer k  ||  LDS prefetch of
+//                 layer k+1's 16 A operands + bias into registers
+// so the matrix pipe never waits for an epilogue or an LDS round trip of its own wave.  An in-order wave only
+// overlaps what is adjacent in its instruction stream, hence the explicit sched_group_barrier interleave
+// (1 MFMA : n VALU : m DS-read) inside every region and a sched_barrier between regions.
+// ---------------------------------------------------------------------------------------------
+struct WFrag {
+    float a[16];    // a[2 * s + mt]
+};
+
+template <bool TRANSPOSED>
+__device__ __forceinline__ WFrag load_wfrag(const float* __restrict__ wl, const LaneOff& lo) {
+    const float* base = wl + (TRANSPOSED ? lo.bwd : lo.fwd);
+    WFrag f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int mtp = s >> 2, rp = s & 3;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + 16 * mt) : (16 * mt * W_STRIDE + 16 * mtp + 4 * rp);
+            f.a[2 * s + mt] = base[off];
+        }
+    }
+    return f;
+}
+
+__device__ __forceinline__ void mfma16(const WFrag& f, const f32x8& in, Acc2& acc) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            acc.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[2 * s + mt], in[s], acc.t[mt], 0, 0, 0);
+}
+
+// interleave pattern of one region: 16 x { 1 MFMA, NV VALU, ND DS reads }, then close the region
+template <int NV, int ND>
+__device__ __forceinline__ void region_end() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ Acc2 acc_add(const Acc2& a, const Acc2& b) {
+    Acc2 r;
+    r.t[0] = a.t[0] + b.t[0];
+    r.t[1] = a.t[1] + b.t[1];
+    return r;
+}
+__device__ __forceinline__ Acc2 acc_zero() {
+    Acc2 r;
+    r.t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return r;
+}
+__device__ __forceinline__ f32x8 masked(const Acc2& z, uint32_t m) {
+    f32x8 v = flat(z);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = ((m >> r) & 1u) ? v[r] : 0.f;
+    return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const float* __restrict__ planes,
+                                              const f32x4 xa, const f32x4 xb, int lane, const DecConst dc, float thr,
+                                              float inv_lb, float (&bce)[2], float (&dx)[2][3]) {
+    const int n = lane & 15, q = lane >> 4;
+    LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
+    asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
+    constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
+    SubGeo geo[2];
+    sub_geometry(geo[0], xa.x, xa.y, xa.z, dc);
+    sub_geometry(geo[1], xb.x, xb.y, xb.z, dc);
+    const float* Wd = W + DEC_OFF_W;
+
+    // weights of the first layer ride along with the gather
+    WFrag A = load_wfrag<false>(Wd, lo);
+    Acc2 B = load_bias(W, 0, lo);
+
+    // ---- gather + forward bilinear sample, one plane (2 x 8 loads) at a time ---------------------------------
+    f32x8 c[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
+#pragma unroll
+    for (int P = 0; P < 3; ++P) {
+        const int a0 = AX0[P], a1 = AX1[P];
+        f32x4 tap[2][4][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* qp = planes + ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SubGeo& g = geo[t];
+            const float wnw = g.w0[a0] * g.w0[a1], wne = g.w1[a0] * g.w0[a1], wsw = g.w0[a0] * g.w1[a1],
+                        wse = g.w1[a0] * g.w1[a1];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = tap[t][0][mt][j] * wnw;
+                    s = fmaf(tap[t][1][mt][j], wne, s);
+                    s = fmaf(tap[t][2][mt][j], wsw, s);
+                    s = fmaf(tap[t][3][mt][j], wse, s);
+                    c[t][4 * mt + j] += s;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    Acc2 net[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                net[t].t[mt][j] = fmaf(wp.z, geo[t].x[2], fmaf(wp.y, geo[t].x[1], fmaf(wp.x, geo[t].x[0], wp.w)));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- forward MLP, software pipelined ---------------------------------------------------------------------
+    uint32_t mask_a[2][NBLK], mask_h[2][NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const float* Wl = Wd + 3 * i * W_LAYER;
+        // fc_c: a = n + fc_c(c)
+        Acc2 a0 = acc_add(B, net[0]), a1 = acc_add(B, net[1]);
+        mfma16(A, c[0], a0);                                                  // R1
+        region_end<0, 0>();
+        const WFrag A0 = load_wfrag<false>(Wl + W_LAYER, lo);                 // R2: prefetch fc_0
+        const Acc2 B0 = load_bias(W, 3 * i + 1, lo);
+        mfma16(A, c[1], a1);
+        const f32x8 af0 = flat(a0);
+        mask_a[0][i] = mask_pos_packed(af0);
+        const f32x8 ra0 = relu8(af0);
+        region_end<2, 1>();
+        Acc2 h0 = B0;                                                          // R3
+        mfma16(A0, ra0, h0);
+        const f32x8 af1 = flat(a1);
+        mask_a[1][i] = mask_pos_packed(af1);
+        const f32x8 ra1 = relu8(af1);
+        region_end<2, 0>();
+        const WFrag A1 = load_wfrag<false>(Wl + 2 * W_LAYER, lo);             // R4: prefetch fc_1
+        const Acc2 B1 = load_bias(W, 3 * i + 2, lo);
+        Acc2 h1 = B0;
+        mfma16(A0, ra1, h1);
+        const f32x8 hf0 = flat(h0);
+        mask_h[0][i] = mask_pos_packed(hf0);
+        const f32x8 rh0 = relu8(hf0);
+        region_end<2, 1>();
+        Acc2 o0 = acc_add(B1, a0);                                             // R5
+        mfma16(A1, rh0, o0);
+        const f32x8 hf1 = flat(h1);
+        mask_h[1][i] = mask_pos_packed(hf1);
+        const f32x8 rh1 = relu8(hf1);
+        region_end<2, 0>();
+        if (i + 1 < NBLK) {                                                    // R6: prefetch next fc_c / first fc_1^T
+            A = load_wfrag<false>(Wl + 3 * W_LAYER, lo);
+            B = load_bias(W, 3 * i + 3, lo);
+        } else {
+            A = load_wfrag<true>(Wl + 2 * W_LAYER, lo);
+        }
+        Acc2 o1 = acc_add(B1, a1);
+        mfma16(A1, rh1, o1);
+        net[0] = o0;
+        net[1] = o1;
+        region_end<0, 1>();
+    }
+    f32x8 wout;
+    {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + lo.q4);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
+    }
+    f32x8 dn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x8 nf = flat(net[t]);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part = fmaf(wout[r], fmaxf(nf[r], 0.f), part);
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float logit = part + W[DEC_OFF_BOUT];
+        float dl;
+        if (MODE == MODE_OPT) {
+            const float e = expf(-fabsf(logit));
+            bce[t] = fmaxf(logit, 0.f) - thr * logit + log1pf(e);
+            const float sig = logit >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            dl = (sig - thr) * inv_lb;
+        } else {
+            bce[t] = logit;
+            dl = 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dn[t][r] = nf[r] > 0.f ? dl * wout[r] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- backward, software pipelined (A holds fc_1[4]^T) ----------------------------------------------------------
+    Acc2 dcc[2] = {acc_zero(), acc_zero()};
+#pragma unroll
+    for (int i = NBLK - 1; i >= 0; --i) {
+        const float* Wl = Wd + 3 * i * W_LAYER;
+        Acc2 z0 = acc_zero();                                                  // R1: fc_1^T dn (sub-tile 0)
+        mfma16(A, dn[0], z0);
+        region_end<0, 0>();
+        const WFrag A0 = load_wfrag<true>(Wl + W_LAYER, lo);                  // R2: prefetch fc_0^T
+        Acc2 z1 = acc_zero();
+        mfma16(A, dn[1], z1);
+        const f32x8 dh0 = masked(z0, mask_h[0][i]);
+        region_end<1, 1>();
+        Acc2 y0 = acc_zero();                                                  // R3: fc_0^T dh (sub-tile 0)
+        mfma16(A0, dh0, y0);
+        const f32x8 dh1 = masked(z1, mask_h[1][i]);
+        region_end<1, 0>();
+        const WFrag Ac = load_wfrag<true>(Wl, lo);                            // R4: prefetch fc_c^T
+        Acc2 y1 = acc_zero();
+        mfma16(A0, dh1, y1);
+        {
+            const f32x8 t = masked(y0, mask_a[0][i]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dn[0][r] += t[r];                      // delta a_i
+        }
+        region_end<1, 1>();
+        mfma16(Ac, dn[0], dcc[0]);                                             // R5: dc += fc_c^T da (sub-tile 0)
+        {
+            const f32x8 t = masked(y1, mask_a[1][i]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dn[1][r] += t[r];
+        }
+        region_end<1, 0>();
+        if (i > 0) A = load_wfrag<true>(Wl - W_LAYER, lo);                    // R6: prefetch fc_1[i-1]^T
+        mfma16(Ac, dn[1], dcc[1]);
+        region_end<0, 1>();
+    }
+    float g[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float d = dn[t][4 * mt + j];
+                g[t][0] = fmaf(wp.x, d, g[t][0]); g[t][1] = fmaf(wp.y, d, g[t][1]); g[t][2] = fmaf(wp.z, d, g[t][2]);
+            }
+        }
+    // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
+    f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
+#pragma unroll
+    for (int P = 0; P < 3; ++P) {
+        const int a0 = AX0[P], a1 = AX1[P];
+        f32x4 tap[2][4][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int off = ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
+            asm volatile("" : "+v"(off));      // opaque: do not CSE with (and keep alive since) the forward gather
+            const float* qp = planes + off;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
+                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
+                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
+                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SubGeo& gg = geo[t];
+            float dnw = 0.f, dne = 0.f, dsw = 0.f, dse = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = dcf[t][4 * mt + j];
+                    dnw = fmaf(tap[t][0][mt][j], d, dnw); dne = fmaf(tap[t][1][mt][j], d, dne);
+                    dsw = fmaf(tap[t][2][mt][j], d, dsw); dse = fmaf(tap[t][3][mt][j], d, dse);
+                }
+            const float gix = (dne - dnw) * gg.w0[a1] + (dse - dsw) * gg.w1[a1];
+            const float giy = (dsw - dnw) * gg.w0[a0] + (dse - dne) * gg.w1[a0];
+            const float sc = (0.5f * (float)(RES - 1)) * 2.f;
+            g[t][a0] += gg.live[a0] * ((gix * sc) / dc.sdiv);
+            g[t][a1] += gg.live[a1] * ((giy * sc) / dc.sdiv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = g[t][a];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            dx[t][a] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // 5-NN + repulsion
 // ---------------------------------------------------------------------------------------------
 struct Top5 {
@@ -854,7 +1199,8 @@ __device__ __forceinline__ void load_dec_image(float* __restrict__ W, const floa
 
 // normalize_batch_pc (opt_defense.py:76-83) on the cloud held in X; two points per thread.
 __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, float* scratch) {
-    const int pa = threadIdx.x, pb = threadIdx.x + OPT_THREADS;
+    const bool owner = threadIdx.x < OPT_THREADS;
+    const int pa = owner ? (int)threadIdx.x : MAXK, pb = owner ? (int)threadIdx.x + OPT_THREADS : MAXK;
     f32x4 a = pa < K ? X[pa] : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 b = pb < K ? X[pb] : f32x4{0.f, 0.f, 0.f, 0.f};
     const float cx = block_sum(a.x + b.x, scratch) / (float)K;
@@ -875,12 +1221,13 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
 // ---------------------------------------------------------------------------------------------
 // NW waves per workgroup (8: 2 per SIMD / 256 VGPRs, 12: 3 per SIMD / 168 VGPRs); threads [0,512) own two points
 // each (kNN + Adam duty), every wave pulls 16-point decoder tiles from an LDS counter.
-template <int NW, bool HOLD>
+template <int NW, int SCHED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
     float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
     const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
     unsigned long long* __restrict__ counters, int K, OptArgs A) {
+    constexpr bool HOLD = SCHED == 0;                    // single 16-point tiles (else 32-point super-tiles)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
     f32x4* X = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // current points
@@ -1012,13 +1359,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                     const int tp = min(tile * 16 + (lane & 15), K - 1);
                     const f32x4 x = X[tp];
                     float logit, bce, dx[3];
-                    decoder_tile<MODE_OPT, true, true>(W, pl, x.x, x.y, x.z, lane, dc, A.threshold, inv_lb, logit, bce, dx);
+                    decoder_tile<MODE_OPT, true, 1>(W, pl, x.x, x.y, x.z, lane, dc, A.threshold, inv_lb, logit, bce, dx);
                     if (lane < 16 && tile * 16 + lane < K) G[tp] = f32x4{dx[0], dx[1], dx[2], bce};
                 } else {             // two 16-point sub-tiles in lock-step
                     const int ia = tile * 32 + (lane & 15), ib = ia + 16;
                     const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
                     float bce[2], dx[2][3];
-                    decoder_tile2<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
+                    if (SCHED == 2)
+                        decoder_tile3<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
+                    else
+                        decoder_tile2<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
                     if (lane < 16) {
                         if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
                         if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
@@ -1135,9 +1485,9 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void decode_kernel(const float* __r
         const float x0 = pc[3 * tp], x1 = pc[3 * tp + 1], x2 = pc[3 * tp + 2];
         float logit, bce, dx[3] = {0.f, 0.f, 0.f};
         if (dlogit_dp != nullptr)
-            decoder_tile<MODE_SUM, true, true>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
+            decoder_tile<MODE_SUM, true, 2>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
         else
-            decoder_tile<MODE_SUM, false, true>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
+            decoder_tile<MODE_SUM, false, 1>(W, pl, x0, x1, x2, lane, dc, 0.f, 1.f, logit, bce, dx);
         if (lane < 16 && tile * 16 + lane < K) {
             logits[(size_t)cloud * K + tp] = logit;
             if (dlogit_dp != nullptr) {
@@ -1221,12 +1571,16 @@ static_assert(OPT_LDS <= 160 * 1024, "LDS budget");
 size_t knn_list_bytes(int B) { return (size_t)B * MAXK * LIST_M * sizeof(uint16_t); }
 
 hipError_t configure_optimize_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
+    if (e != hipSuccess) return e;
+
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
     return e;
@@ -1235,25 +1589,21 @@ hipError_t configure_optimize_kernels() {
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
                            float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
                            unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s) {
-    if (a.variant == 1)
-        hipLaunchKernelGGL((optimize_kernel<8, false>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
+    if (a.variant == 2)
+        hipLaunchKernelGGL((optimize_kernel<8, 2>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
+                           loss_batch_per_cloud, knn_lists, counters, K, a);
+    else if (a.variant == 1)
+        hipLaunchKernelGGL((optimize_kernel<8, 1>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
                            loss_batch_per_cloud, knn_lists, counters, K, a);
     else
-        hipLaunchKernelGGL((optimize_kernel<8, true>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
+        hipLaunchKernelGGL((optimize_kernel<8, 0>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
                            loss_batch_per_cloud, knn_lists, counters, K, a);
     return hipGetLastError();
 }
 
 hipError_t launch_decode(const float* dec_img, const float* planes, const float* p, int B, int K,
                          float* logits, float* dlogit_dp, DecConst dc, hipStream_t s) {
-    int threads = OPT_THREADS;
-    if (const char* e = getenv("IFD_DEC_THREADS")) threads = atoi(e);      // experiment hook: waves per workgroup
-    size_t lds = DEC_LDS;
-    if (const char* e = getenv("IFD_DEC_LDS")) {                           // experiment hook: force 1 workgroup / CU
-        lds = (size_t)atoi(e);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    hipLaunchKernelGGL(decode_kernel, dim3(B), dim3(threads), lds, s, dec_img, planes, p, K, logits,
+    hipLaunchKernelGGL(decode_kernel, dim3(B), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K, logits,
                        dlogit_dp, dc);
     return hipGetLastError();
 }
