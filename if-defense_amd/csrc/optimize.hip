@@ -86,10 +86,13 @@ __device__ __forceinline__ uint32_t mask_pos(const f32x8& v) {
     return m;
 }
 
+// ReLU as an integer max on the float bits: one v_max_i32 instead of hipcc's canonicalise + v_max_f32 pair
+// (negative floats, -0.0 included, are negative integers; positive floats keep their bits; MFMA never yields NaN
+// from finite inputs here).
 __device__ __forceinline__ f32x8 relu8(const f32x8& v) {
     f32x8 o;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) o[r] = fmaxf(v[r], 0.f);
+    for (int r = 0; r < 8; ++r) o[r] = __int_as_float(max(__float_as_int(v[r]), 0));
     return o;
 }
 
