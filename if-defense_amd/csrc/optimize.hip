@@ -1002,119 +1002,172 @@ __device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, in
 //       certificate violated -> this wave runs the exact brute-force scan for this step.
 //   Either way every step uses the exact 5-NN set; ties follow ascending j like the scan.
 // ---------------------------------------------------------------------------------------------
-#ifndef IFD_LIST_M
-#define IFD_LIST_M 32
-#endif
-constexpr int LIST_M = IFD_LIST_M;       // entries per point (uint16), lists live in global memory (L2)
-constexpr int STAGE_M = 16;              // LDS staging entries per point during a rebuild (32 B)
+constexpr int LIST_F = 16;               // "front": every point within rho_f at build time (evaluated every step)
+constexpr int LIST_B = 32;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
+constexpr int LIST_M = LIST_F + LIST_B;  // uint16 entries per point; lists live in global memory (L2-resident)
 
-// 5 nearest of points ia / ib among their lists (global memory, entries [0,cnt) valid); the two independent
-// insertion chains are interleaved for ILP.  cnt < 0 (no list) leaves the result at +inf.
+// 5 nearest of points ia / ib among entries [E0, E1) of their lists, continuing the running top-5 in ta / tb.
+// The two independent insertion chains are interleaved for ILP.  Entries >= cnt are ignored.
+template <int E0, int E1>
 __device__ __forceinline__ void list_top5_2(const f32x4* __restrict__ X, const uint16_t* La, const uint16_t* Lb,
                                             int cnt_a, int cnt_b, int ia, int ib, Top5& ta, Top5& tb) {
+    constexpr int NC = (E1 - E0) / 8;
     const f32x4 xa = X[ia], xb = X[ib];
-    top5_init(ta);
-    top5_init(tb);
+    u32x4 wa[NC], wb[NC];
 #pragma unroll
-    for (int c = 0; c < LIST_M / 8; ++c) {
+    for (int c = 0; c < NC; ++c) {
+        wa[c] = reinterpret_cast<const u32x4*>(La)[E0 / 8 + c];
+        wb[c] = reinterpret_cast<const u32x4*>(Lb)[E0 / 8 + c];
+    }
+    // One entry of each list per block.  The sched_barrier keeps every compare next to the selects that consume
+    // it: left alone, the scheduler runs the distance chains ahead and parks dozens of lane masks in spilled SGPRs
+    // (v_writelane / v_readlane + s_nop per compare - 2x the instructions).  The next entry's coordinates are
+    // fetched one block ahead to cover the LDS latency.
+    int ja = (int)(wa[0][0] & 0xffffu), jb = (int)(wb[0][0] & 0xffffu);
+    bool va = E0 < cnt_a, vb = E0 < cnt_b;
+    f32x4 na = X[va ? ja : ia], nb = X[vb ? jb : ib];
+#pragma unroll
+    for (int e = E0; e < E1; ++e) {
+        const f32x4 pa_ = na, pb_ = nb;
+        const int cja = ja, cjb = jb;
+        const bool cva = va, cvb = vb;
+        if (e + 1 < E1) {
+            const int r = e + 1 - E0;
+            const unsigned int pka = wa[r >> 3][(r & 7) >> 1], pkb = wb[r >> 3][(r & 7) >> 1];
+            ja = (r & 1) ? (int)(pka >> 16) : (int)(pka & 0xffffu);
+            jb = (r & 1) ? (int)(pkb >> 16) : (int)(pkb & 0xffffu);
+            va = e + 1 < cnt_a;
+            vb = e + 1 < cnt_b;
+            na = X[va ? ja : ia];
+            nb = X[vb ? jb : ib];
+        }
+        const float ax = pa_.x - xa.x, ay = pa_.y - xa.y, az = pa_.z - xa.z;
+        const float bx = pb_.x - xb.x, by = pb_.y - xb.y, bz = pb_.z - xb.z;
+        float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
+        float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
+        da = cva ? da : INFINITY;
+        db = cvb ? db : INFINITY;
+        top5_insert_nb(ta, da, cja);
+        top5_insert_nb(tb, db, cjb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- fast evaluation: 32-bit keys = (distance bits with the low 10 mantissa bits replaced by the index) --------
+// Positive floats order like their bit patterns, so a running sorted top-6 of keys needs one v_min_u32 and five
+// v_med3_u32 per entry - no compare masks, no index selects (16 instead of ~33 VALU ops per entry).  The 5 smallest
+// keys are EXACTLY the 5 nearest entries whenever key 5 and key 6 differ above the index bits (every other entry
+// is then strictly farther than all five); otherwise (relative distance gap < 2^-13 at the 5/6 boundary, rare) the
+// caller falls back to the exact insertion path.  The order inside the five is irrelevant: the gradient sums are
+// fixed-point (rep_point).  Unused list slots hold index MAXK, the far-away dummy point X[MAXK].
+constexpr unsigned int KEY_IDX_MASK = 1023u;
+struct Keys6 {
+    unsigned int k0, k1, k2, k3, k4, k5;
+};
+__device__ __forceinline__ void keys6_init(Keys6& q) { q.k0 = q.k1 = q.k2 = q.k3 = q.k4 = q.k5 = 0xffffffffu; }
+__device__ __forceinline__ unsigned int umed3(unsigned int a, unsigned int b, unsigned int c) {
+    unsigned int r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void keys6_insert(Keys6& q, unsigned int x) {
+    q.k5 = umed3(q.k4, q.k5, x);      // new k_i = median(old k_{i-1}, old k_i, x)
+    q.k4 = umed3(q.k3, q.k4, x);
+    q.k3 = umed3(q.k2, q.k3, x);
+    q.k2 = umed3(q.k1, q.k2, x);
+    q.k1 = umed3(q.k0, q.k1, x);
+    q.k0 = min(q.k0, x);
+}
+template <int E0, int E1>
+__device__ __forceinline__ void list_keys6_2(const f32x4* __restrict__ X, const uint16_t* La, const uint16_t* Lb,
+                                             int ia, int ib, Keys6& qa, Keys6& qb) {
+    const f32x4 xa = X[ia], xb = X[ib];
+#pragma unroll
+    for (int c = E0 / 8; c < E1 / 8; ++c) {
         const u32x4 wa = reinterpret_cast<const u32x4*>(La)[c], wb = reinterpret_cast<const u32x4*>(Lb)[c];
 #pragma unroll
         for (int e8 = 0; e8 < 8; ++e8) {
-            const int e = c * 8 + e8;
             const unsigned int pka = wa[e8 >> 1], pkb = wb[e8 >> 1];
-            const int ja = (e8 & 1) ? (int)(pka >> 16) : (int)(pka & 0xffffu);
-            const int jb = (e8 & 1) ? (int)(pkb >> 16) : (int)(pkb & 0xffffu);
-            const bool va = e < cnt_a, vb = e < cnt_b;
-            const f32x4 pa_ = X[va ? ja : ia], pb_ = X[vb ? jb : ib];
+            const unsigned int ja = (e8 & 1) ? (pka >> 16) : (pka & 0xffffu);
+            const unsigned int jb = (e8 & 1) ? (pkb >> 16) : (pkb & 0xffffu);
+            const f32x4 pa_ = X[ja], pb_ = X[jb];
             const float ax = pa_.x - xa.x, ay = pa_.y - xa.y, az = pa_.z - xa.z;
             const float bx = pb_.x - xb.x, by = pb_.y - xb.y, bz = pb_.z - xb.z;
-            float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
-            float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
-            da = va ? da : INFINITY;
-            db = vb ? db : INFINITY;
-            top5_insert_nb(ta, da, ja);
-            top5_insert_nb(tb, db, jb);
-        }
-    }
-}
-
-// Append candidate j to a point's list: entries are staged in the lane's private 32-byte LDS slot and
-// flushed to the global list as whole 32-byte chunks (2-byte global stores from 64 divergent lanes cost
-// ~270 us per rebuild; chunked they are noise).  n counts all candidates, stored or not.
-__device__ __forceinline__ void list_append(uint16_t* __restrict__ stage, uint16_t* __restrict__ lst, int& n, int j) {
-    if (n < LIST_M) {
-        stage[n & (STAGE_M - 1)] = (uint16_t)j;
-        if ((n & (STAGE_M - 1)) == STAGE_M - 1) {
-            const u32x4* sp = reinterpret_cast<const u32x4*>(stage);
-            u32x4* gp = reinterpret_cast<u32x4*>(lst + (n & ~(STAGE_M - 1)));
-            gp[0] = sp[0];
-            gp[1] = sp[1];
-        }
-    }
-    ++n;
-}
-__device__ __forceinline__ void list_flush_tail(const uint16_t* __restrict__ stage, uint16_t* __restrict__ lst, int n) {
-    if (n < LIST_M && (n & (STAGE_M - 1)) != 0) {
-        const u32x4* sp = reinterpret_cast<const u32x4*>(stage);
-        u32x4* gp = reinterpret_cast<u32x4*>(lst + (n & ~(STAGE_M - 1)));
-        gp[0] = sp[0];
-        gp[1] = sp[1];
-    }
-}
-
-// (Re)build the lists of the two points owned by each lane of this wave.  r5sq_* are upper bounds of the
-// squared 5-NN distances (INFINITY = unknown -> exact brute-force scan first, results left in ta/tb).  al_*
-// (alpha^2) adapt: shrink in proportion to the overshoot and retry when a ball holds > LIST_M points, grow
-// slowly when it is sparsely filled.  cnt_* = -1 on return means "ball too crowded, no list".  Returns #passes.
-struct KnnPt {
-    int cnt;        // valid list entries, -1 = no list
-    float rho;      // the list holds every point that was within rho of x0 at build time
-    float al;       // alpha^2: rho^2 = al * (upper bound of the squared 5-NN distance)
-    f32x4 x0;       // position at build time
-};
-
-__device__ __forceinline__ int knn_rebuild(const f32x4* __restrict__ X, int K, int pa, int pb,
-                                           uint16_t* __restrict__ La, uint16_t* __restrict__ Lb,
-                                           uint16_t* __restrict__ Sa, uint16_t* __restrict__ Sb, float r5sq_a,
-                                           float r5sq_b, Top5& ta, Top5& tb, KnnPt& ka, KnnPt& kb) {
-    if (__any(!(r5sq_a < INFINITY) || !(r5sq_b < INFINITY))) {
-        knn_scan2(X, K, pa, pb, ta, tb);
-        r5sq_a = ta.d4;
-        r5sq_b = tb.d4;
-    }
-    const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
-    int na = 0, nb = 0, passes = 0;
-    float tha = 0.f, thb = 0.f;
-#pragma unroll 1
-    for (int tries = 0; tries < 4; ++tries) {
-        tha = r5sq_a * ka.al;
-        thb = r5sq_b * kb.al;
-        na = nb = 0;
-        ++passes;
-#pragma unroll 4
-        for (int j = 0; j < K; ++j) {
-            const f32x4 xj = X[j];
-            const float ax = xj.x - xa.x, ay = xj.y - xa.y, az = xj.z - xa.z;
-            const float bx = xj.x - xb.x, by = xj.y - xb.y, bz = xj.z - xb.z;
             const float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
             const float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
-            if (da < tha && j != pa) list_append(Sa, La, na, j);
-            if (db < thb && j != pb) list_append(Sb, Lb, nb, j);
+            keys6_insert(qa, (__float_as_uint(da) & ~KEY_IDX_MASK) | ja);
+            keys6_insert(qb, (__float_as_uint(db) & ~KEY_IDX_MASK) | jb);
         }
-        const bool ova = na > LIST_M, ovb = nb > LIST_M;
-        if (!__any(ova || ovb)) break;
-        ka.al = ova ? fmaxf(ka.al * ((float)LIST_M / (float)na) * 0.8f, 1.08f) : ka.al;
-        kb.al = ovb ? fmaxf(kb.al * ((float)LIST_M / (float)nb) * 0.8f, 1.08f) : kb.al;
     }
-    list_flush_tail(Sa, La, na);
-    list_flush_tail(Sb, Lb, nb);
-    ka.cnt = na <= LIST_M ? na : -1;
-    kb.cnt = nb <= LIST_M ? nb : -1;
-    ka.rho = sqrtf(tha);
-    kb.rho = sqrtf(thb);
-    ka.al = na < (LIST_M * 2) / 5 ? fminf(ka.al * 1.15f, 25.f) : ka.al;
-    kb.al = nb < (LIST_M * 2) / 5 ? fminf(kb.al * 1.15f, 25.f) : kb.al;
-    return passes;
+}
+// upper bound of the squared distance of key k (INF for the init value / NaN patterns)
+__device__ __forceinline__ float key_d_upper(unsigned int k) {
+    return k >= 0x7f800000u ? INFINITY : __uint_as_float(k | KEY_IDX_MASK);
+}
+__device__ __forceinline__ bool keys6_ambiguous(const Keys6& q) { return ((q.k4 ^ q.k5) & ~KEY_IDX_MASK) == 0u; }
+__device__ __forceinline__ void keys6_to_top5(const Keys6& q, Top5& t) {
+    t.i0 = (int)(q.k0 & KEY_IDX_MASK); t.i1 = (int)(q.k1 & KEY_IDX_MASK); t.i2 = (int)(q.k2 & KEY_IDX_MASK);
+    t.i3 = (int)(q.k3 & KEY_IDX_MASK); t.i4 = (int)(q.k4 & KEY_IDX_MASK);
+    t.d0 = t.d1 = t.d2 = t.d3 = 0.f;
+    t.d4 = key_d_upper(q.k4);
+}
+
+// Per-point list state kept by the owning lane.
+struct KnnPt {
+    int cnt_f, cnt_b;   // valid entries of the front / back segment; cnt_b = -1: no valid list (ball too crowded)
+    float rho_f;        // the front holds EVERY point that was within rho_f at build time (0: front not complete)
+    float rho_b;        // front + back hold every point that was within rho_b at build time
+    float al_f, al_b;   // alpha^2 of the two radii: rho^2 = al * (upper bound of the squared 5-NN distance)
+    f32x4 x0;           // position at build time
+};
+
+// Wave-cooperative ("transposed") list build: the lanes hold the K candidate points in registers (16 each), the
+// wave walks over its 128 target points; for each target one distance per candidate, hits are compacted with
+// ballot / mbcnt into the target's list - no divergent branches, exact counts, one pass.  TF / TB (LDS) hold the
+// squared front / back radii per point, CF / CB (LDS) receive the hit counts (saturated at 255).
+__device__ __forceinline__ void knn_build_lists(const f32x4* __restrict__ X, int K, int wave, int lane,
+                                                uint16_t* __restrict__ lists, const float* __restrict__ TF,
+                                                const float* __restrict__ TB, uint8_t* __restrict__ CF,
+                                                uint8_t* __restrict__ CB, bool overflowed_only) {
+    float cx[16], cy[16], cz[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = lane + 64 * k;
+        const f32x4 p = X[min(j, K - 1)];
+        const bool v = j < K;
+        cx[k] = v ? p.x : 1e18f; cy[k] = v ? p.y : 1e18f; cz[k] = v ? p.z : 1e18f;
+    }
+#pragma unroll 1
+    for (int ii = 0; ii < 128; ++ii) {
+        const int i = ((ii & 64) ? OPT_THREADS : 0) + wave * 64 + (ii & 63);     // the points this wave's lanes own
+        if (i >= K) continue;                                                      // wave-uniform
+        if (overflowed_only && CF[i] <= LIST_F && CB[i] <= LIST_B) continue;       // wave-uniform (LDS broadcast)
+        const f32x4 xi = X[i];
+        const float tf = TF[i], tb = TB[i];
+        uint16_t* lst = lists + (size_t)i * LIST_M;
+        int nf = 0, nb = 0;                                                        // wave-uniform running counts
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = lane + 64 * k;
+            const float ex = cx[k] - xi.x, ey = cy[k] - xi.y, ez = cz[k] - xi.z;
+            const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            const bool in_b = d < tb && j != i;
+            const bool in_f = d < tf && in_b;
+            const unsigned long long mf = __ballot(in_f);
+            int pos_f = nf + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
+            const bool to_f = in_f && pos_f < LIST_F;
+            if (to_f) lst[pos_f] = (uint16_t)j;
+            nf += __popcll(mf);
+            const bool to_b = in_b && !to_f;                  // ring members + front hits that did not fit
+            const unsigned long long mb = __ballot(to_b);
+            const int pos_b = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+            if (to_b && pos_b < LIST_B) lst[LIST_F + pos_b] = (uint16_t)j;
+            nb += __popcll(mb);
+        }
+        // unused slots point at the dummy X[MAXK] (the key evaluation does not look at counts)
+        if (lane < LIST_M && lane >= (lane < LIST_F ? nf : LIST_F + nb)) lst[lane] = (uint16_t)MAXK;
+        if (lane == 0) { CF[i] = (uint8_t)min(nf, 255); CB[i] = (uint8_t)min(nb, 255); }
+    }
 }
 
 struct RepConst {
@@ -1124,12 +1177,12 @@ struct RepConst {
 // Loss and gradient terms of one centre point (repulsion_loss.py:43-53).  The centre part is
 // returned in gc (un-scaled), neighbour parts go to the fixed-point LDS accumulator.
 __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long* __restrict__ F, int i,
-                                          const Top5& t, const RepConst rc, float& loss, float (&gc)[3],
+                                          const Top5& t, const RepConst rc, float& loss, long long (&gc)[3],
                                           bool want_grad) {
     const f32x4 xi = X[i];
     const int idx[5] = {t.i0, t.i1, t.i2, t.i3, t.i4};
     loss = 0.f;
-    gc[0] = gc[1] = gc[2] = 0.f;
+    gc[0] = gc[1] = gc[2] = 0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int j = idx[k];
@@ -1146,13 +1199,14 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
             const float dd = -w - (rc.radius - d) * w * (2.f * q / rc.h);
             const float coef = d2raw > rc.eps ? dd / d : 0.f;
             const float gx = coef * ex, gy = coef * ey, gz = coef * ez;
-            gc[0] -= gx; gc[1] -= gy; gc[2] -= gz;
-            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 0),
-                      (unsigned long long)__float2ll_rn(gx * FIX_SCALE));
-            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 1),
-                      (unsigned long long)__float2ll_rn(gy * FIX_SCALE));
-            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 2),
-                      (unsigned long long)__float2ll_rn(gz * FIX_SCALE));
+            // fixed point on both ends: the sums do not depend on the order of the neighbours or of the atomics,
+            // and the centre receives exactly minus what its neighbours receive
+            const long long fx = __float2ll_rn(gx * FIX_SCALE), fy = __float2ll_rn(gy * FIX_SCALE),
+                            fz = __float2ll_rn(gz * FIX_SCALE);
+            gc[0] -= fx; gc[1] -= fy; gc[2] -= fz;
+            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 0), (unsigned long long)fx);
+            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 1), (unsigned long long)fy);
+            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 2), (unsigned long long)fz);
         }
     }
 }
@@ -1233,11 +1287,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     constexpr bool HOLD = SCHED == 0;                    // single 16-point tiles (else 32-point super-tiles)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
-    f32x4* X = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // current points
-    f32x4* G = X + MAXK;                                             // occupancy gradient (+ BCE term in .w)
-    long long* F = reinterpret_cast<long long*>(G + MAXK);           // fixed-point neighbour-gradient scatter
-    uint16_t* L = reinterpret_cast<uint16_t*>(F + 3 * MAXK);         // list staging [MAXK][STAGE_M] (rebuilds)
-    float* scratch = reinterpret_cast<float*>(L + MAXK * STAGE_M);   // 128 floats
+    f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
+    f32x4* X = G + MAXK;                                             // current points; X[MAXK] = far-away dummy
+    long long* F = reinterpret_cast<long long*>(X + MAXK + 1);       // fixed-point neighbour-gradient scatter
+    float* TF = reinterpret_cast<float*>(F + 3 * MAXK);              // squared front radius per point (list builds)
+    float* TB = TF + MAXK;                                           // squared back radius per point
+    uint8_t* CF = reinterpret_cast<uint8_t*>(TB + MAXK);             // hit counts written by the build
+    uint8_t* CB = CF + MAXK;
+    float* scratch = reinterpret_cast<float*>(CB + MAXK);            // 128 floats
 
     const int cloud = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1267,6 +1324,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
     }
     for (int i = tid; i < MAXK * 3; i += NW * 64) F[i] = 0;
+    if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 0.f};
 
     const DecConst dc = A.dc;
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
@@ -1279,15 +1337,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     // certified neighbour lists of the two owned points
     uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;   // global (L2-resident)
     uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + (pb & (MAXK - 1))) * LIST_M;
-    uint16_t* Sa = L + (pa & (MAXK - 1)) * STAGE_M;                          // LDS staging slots (rebuilds)
-    uint16_t* Sb = L + (pb & (MAXK - 1)) * STAGE_M;
-    KnnPt ka = {-1, 0.f, 0.16f * LIST_M, f32x4{0.f, 0.f, 0.f, 0.f}};         // al: ~80 % fill on a flat patch
+    KnnPt ka = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}};    // ~10 front / ~35 total hits on a flat patch
     KnnPt kb = ka;
+    uint16_t* cloud_lists = knn_lists + (size_t)cloud * MAXK * LIST_M;
     float* dmaxbuf = scratch + 32;                                   // [2][MAX_WAVES] per-wave max |x - x0| (next step)
     float* movebuf = scratch + 64;                                   // [2][MAX_WAVES] per-wave max single-step move
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
     int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
-    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0;
+    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0, n_tier2 = 0, n_exact = 0;
+#ifdef IFD_PROF      // cycle accounting of cloud 0 (diagnostic builds only; overwrites the counters)
+    unsigned long long pc_build = 0, pc_eval = 0, pc_rep = 0, pc_tiles = 0, pc_wait = 0, pc_adam = 0, pc_t = 0;
+#define PROF_T0() pc_t = __builtin_readcyclecounter()
+#define PROF_ACC(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); v += n_ - pc_t; pc_t = n_; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ACC(v)
+#endif
     if (tid < 2) rebuild_flag[tid] = 0;
     if (tid == 0) *tile_ctr = 0;
     if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
@@ -1295,7 +1360,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
-        float gca[3] = {0.f, 0.f, 0.f}, gcb[3] = {0.f, 0.f, 0.f};
+        long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
         // Work of one step: ntiles decoder tiles (pulled from an LDS counter by every wave) + the kNN/repulsion of
         // the 8 owner waves.  Waves 4-7 do their kNN first, waves 0-3 after a few tiles, so that each SIMD always
         // has MFMA work queued next to the VALU-only kNN; waves >= 8 (3-per-SIMD configuration) only pull tiles.
@@ -1319,38 +1384,163 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                     }
                     // the certificate must survive one more step: r5 grows <= 2 mv, both displacements <= mv
                     const float soft_slack = 6.f * mv;
-#pragma unroll 1
-                    for (int attempt = 0;; ++attempt) {
-                        list_top5_2(X, La, Lb, ka.cnt, kb.cnt, ia, ib, ta, tb);
-                        if (!force || attempt == 1) break;
+                    PROF_T0();
+                    if (force) {
+                        // ---- synchronous rebuild (every owner wave, this step) ------------------------------------
                         ++n_rebuild;
-                        n_pass += knn_rebuild(X, K, pa, pb, La, Lb, Sa, Sb, ta.d4, tb.d4, ta, tb, ka, kb);
-                        ka.x0 = X[ia];
-                        kb.x0 = X[ib];
+                        // upper bounds of the squared 5-NN distances: any 5 members of the current lists at their
+                        // present positions (a truncated back segment still holds valid points), else the exact scan
+                        bool have = step != 0;
+                        if (have) {
+                            Keys6 qa, qb;
+                            keys6_init(qa);
+                            keys6_init(qb);
+                            list_keys6_2<0, LIST_M>(X, La, Lb, ia, ib, qa, qb);
+                            ta.d4 = key_d_upper(qa.k4);
+                            tb.d4 = key_d_upper(qb.k4);
+                            have = ta.d4 < 1e30f && tb.d4 < 1e30f;       // the dummy point is ~3e36 away
+                        }
+                        if (!__all(have)) {
+                            ++n_pass;
+                            knn_scan2(X, K, pa, pb, ta, tb);
+                        }
+                        if (pa < K) { TF[pa] = ta.d4 * ka.al_f; TB[pa] = ta.d4 * ka.al_b; }
+                        if (pb < K) { TF[pb] = tb.d4 * kb.al_f; TB[pb] = tb.d4 * kb.al_b; }
+                        __builtin_amdgcn_wave_barrier();          // this wave's lanes wrote, this wave reads (LDS is in order)
+                        knn_build_lists(X, K, wave, lane, cloud_lists, TF, TB, CF, CB, false);
+                        __builtin_amdgcn_wave_barrier();
+                        // overflowed balls: shrink the radius in proportion to the overshoot (hit count ~ r^2 on a
+                        // surface) and rebuild just those points; whatever still overflows is served by the scan
+#pragma unroll 1
+                        for (int rep = 0; rep < 3; ++rep) {
+                            bool redo = false;
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq) {
+                                const int pt = qq ? pb : pa;
+                                if (pt < K) {
+                                    const int nf = CF[pt], nb = CB[pt];
+                                    if (nf > LIST_F || nb > LIST_B) {
+                                        float tf = TF[pt], tb2 = TB[pt];
+                                        const float n_in = (float)(min(nf, LIST_F) + nb);       // points inside the back radius
+                                        float nf_new = (float)nf;
+                                        if (nf > LIST_F) { tf *= (0.7f * LIST_F) / (float)nf; nf_new = 0.7f * LIST_F; }
+                                        if (n_in - nf_new > 0.85f * LIST_B) tb2 *= (nf_new + 0.75f * LIST_B) / n_in;
+                                        tb2 = fmaxf(tb2, tf);
+                                        TF[pt] = tf; TB[pt] = tb2;
+                                        redo = true;
+                                    }
+                                }
+                            }
+                            if (!__any(redo)) break;
+                            ++n_pass;
+                            __builtin_amdgcn_wave_barrier();
+                            knn_build_lists(X, K, wave, lane, cloud_lists, TF, TB, CF, CB, true);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            KnnPt& kp = qq ? kb : ka;
+                            const int pt = qq ? pb : pa;
+                            const float d4 = qq ? tb.d4 : ta.d4;
+                            if (pt < K) {
+                                const int nf = CF[pt], nb = CB[pt];
+                                const float tf = TF[pt], tb2 = TB[pt];
+                                kp.cnt_f = min(nf, LIST_F);
+                                kp.rho_f = nf <= LIST_F ? sqrtf(tf) : 0.f;          // front complete only if everything fitted
+                                kp.cnt_b = nb <= LIST_B ? nb : -1;
+                                kp.rho_b = sqrtf(tb2);
+                                // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly
+                                // when sparsely filled
+                                if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb2 / d4; }
+                                if (nf < LIST_F / 2) kp.al_f *= 1.15f;
+                                if (nf + nb < LIST_M / 2) kp.al_b *= 1.15f;
+                                kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
+                                kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
+                                kp.al_f = fminf(kp.al_f, kp.al_b);
+                                kp.x0 = X[pt];
+                            }
+                        }
                         dmax = 0.f;
                     }
+                    PROF_ACC(pc_build);
+                    // ---- tier 1: the front ball -----------------------------------------------------------------
                     const f32x4 xa = X[ia], xb = X[ib];
                     const float da0 = sqrtf((xa.x - ka.x0.x) * (xa.x - ka.x0.x) + (xa.y - ka.x0.y) * (xa.y - ka.x0.y) +
                                             (xa.z - ka.x0.z) * (xa.z - ka.x0.z));
                     const float db0 = sqrtf((xb.x - kb.x0.x) * (xb.x - kb.x0.x) + (xb.y - kb.x0.y) * (xb.y - kb.x0.y) +
                                             (xb.z - kb.x0.z) * (xb.z - kb.x0.z));
-                    // every point outside the list is farther than this bound (build radius minus both moves)
-                    const float bnd_a = (ka.rho - da0 - dmax) * 0.99999f - 1e-7f;
-                    const float bnd_b = (kb.rho - db0 - dmax) * 0.99999f - 1e-7f;
-                    const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
-                    const bool hard = (pa >= K || (ka.cnt >= 0 && r5a < bnd_a)) && (pb >= K || (kb.cnt >= 0 && r5b < bnd_b));
-                    const bool soft_a = pa >= K || ka.cnt < 0 || r5a < bnd_a - soft_slack;
-                    const bool soft_b = pb >= K || kb.cnt < 0 || r5b < bnd_b - soft_slack;
-                    if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
-                        ++n_brute;
-                        knn_scan2(X, K, pa, pb, ta, tb);
+                    bool exact = last;       // the reported loss sums the five terms in ascending-distance order
+                    bool soft_ok = true;
+                    if (!exact) {
+                        // ---- fast path: key networks (see list_keys6_2) ------------------------------------------
+                        Keys6 qa, qb;
+                        keys6_init(qa);
+                        keys6_init(qb);
+                        list_keys6_2<0, LIST_F>(X, La, Lb, ia, ib, qa, qb);
+                        float r5a = sqrtf(key_d_upper(qa.k4)), r5b = sqrtf(key_d_upper(qb.k4));
+                        const bool ok1 = (pa >= K || r5a < (ka.rho_f - da0 - dmax) * 0.99999f - 1e-7f) &&
+                                         (pb >= K || r5b < (kb.rho_f - db0 - dmax) * 0.99999f - 1e-7f);
+                        bool scanned = false;
+                        if (!__all(ok1)) {
+                            ++n_tier2;
+                            list_keys6_2<LIST_F, LIST_M>(X, La, Lb, ia, ib, qa, qb);
+                            r5a = sqrtf(key_d_upper(qa.k4));
+                            r5b = sqrtf(key_d_upper(qb.k4));
+                            const float bnd_a = (ka.rho_b - da0 - dmax) * 0.99999f - 1e-7f;
+                            const float bnd_b = (kb.rho_b - db0 - dmax) * 0.99999f - 1e-7f;
+                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < bnd_a)) && (pb >= K || (kb.cnt_b >= 0 && r5b < bnd_b));
+                            if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
+                                ++n_brute;
+                                knn_scan2(X, K, pa, pb, ta, tb);
+                                scanned = true;
+                            }
+                            soft_ok = (pa >= K || ka.cnt_b < 0 || r5a < bnd_a - soft_slack) &&
+                                      (pb >= K || kb.cnt_b < 0 || r5b < bnd_b - soft_slack);
+                        }
+                        if (!scanned) {
+                            const bool amb = (pa < K && keys6_ambiguous(qa)) || (pb < K && keys6_ambiguous(qb));
+                            if (__any(amb)) {
+                                exact = true;
+                            } else {
+                                keys6_to_top5(qa, ta);
+                                keys6_to_top5(qb, tb);
+                            }
+                        }
                     }
-                    // crowded balls (cnt < 0) can only be served by the scan; they do not ask for rebuilds
-                    if (__any(!(soft_a && soft_b)) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
+                    if (exact) {
+                        // ---- exact path: sorted insertion with indices (last step, near-ties) --------------------
+                        ++n_exact;
+                        soft_ok = true;
+                        top5_init(ta);
+                        top5_init(tb);
+                        list_top5_2<0, LIST_F>(X, La, Lb, ka.cnt_f, kb.cnt_f, ia, ib, ta, tb);
+                        // every point outside a ball of build radius rho is now farther than rho - (both displacements)
+                        const bool ok1 = (pa >= K || sqrtf(ta.d4) < (ka.rho_f - da0 - dmax) * 0.99999f - 1e-7f) &&
+                                         (pb >= K || sqrtf(tb.d4) < (kb.rho_f - db0 - dmax) * 0.99999f - 1e-7f);
+                        if (!__all(ok1)) {
+                            // ---- tier 2: add the ring -----------------------------------------------------------------
+                            list_top5_2<LIST_F, LIST_M>(X, La, Lb, LIST_F + ka.cnt_b, LIST_F + kb.cnt_b, ia, ib, ta, tb);
+                            const float bnd_a = (ka.rho_b - da0 - dmax) * 0.99999f - 1e-7f;
+                            const float bnd_b = (kb.rho_b - db0 - dmax) * 0.99999f - 1e-7f;
+                            const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
+                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < bnd_a)) && (pb >= K || (kb.cnt_b >= 0 && r5b < bnd_b));
+                            if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
+                                ++n_brute;
+                                knn_scan2(X, K, pa, pb, ta, tb);
+                            }
+                            // crowded balls (cnt_b < 0) can only be served by the scan; they do not ask for rebuilds
+                            soft_ok = (pa >= K || ka.cnt_b < 0 || r5a < bnd_a - soft_slack) &&
+                                      (pb >= K || kb.cnt_b < 0 || r5b < bnd_b - soft_slack);
+                        }
+                    }
+                    if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
+                    PROF_ACC(pc_eval);
                 }
                 if (pa < K) rep_point(X, F, pa, ta, rc, rep_loss_a, gca, true);
                 if (pb < K) rep_point(X, F, pb, tb, rc, rep_loss_b, gcb, true);
+                PROF_ACC(pc_rep);
             }
+            PROF_T0();
             // decoder tiles: phase 0 = up to `quota` tiles before the kNN, phase 1 = until the step's tiles run out
 #pragma unroll 1
             for (int n = 0; phase == 1 || n < quota; ++n) {
@@ -1378,8 +1568,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                     }
                 }
             }
+            PROF_ACC(pc_tiles);
         }
         __syncthreads();
+        PROF_ACC(pc_wait);
         if (last && loss_out != nullptr) {   // losses at the pre-update points of the last step
             float occ = (pa < K ? G[pa].w : 0.f) + (pb < K ? G[pb].w : 0.f);
             float rep = (pa < K ? rep_loss_a : 0.f) + (pb < K ? rep_loss_b : 0.f);
@@ -1412,9 +1604,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 float msq = 0.f;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const float gn = __ll2float_rn(F[3 * pt + a]) * FIX_INV;
+                    const float gn = __ll2float_rn(F[3 * pt + a] + (q ? gcb[a] : gca[a])) * FIX_INV;
                     F[3 * pt + a] = 0;
-                    const float gr = ((q ? gcb[a] : gca[a]) + gn) * rep_scale;
+                    const float gr = gn * rep_scale;
                     const float g = gocc[a] + gr;
                     float& mr = mm[3 * q + a];
                     float& vr = vv[3 * q + a];
@@ -1441,13 +1633,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
         if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
         __syncthreads();
+        PROF_ACC(pc_adam);
     }
 
     if (counters != nullptr && lane == 0) {
         atomicAdd(counters + 0, (unsigned long long)n_rebuild);   // wave-level list rebuilds
         atomicAdd(counters + 1, (unsigned long long)n_brute);     // wave-level certificate failures (exact scans)
-        atomicAdd(counters + 2, (unsigned long long)n_pass);      // wave-level candidate-collection passes
+        atomicAdd(counters + 2, (unsigned long long)n_pass);      // extra rebuild work: exact scans for radii + overflow re-passes
+        atomicAdd(counters + 4, (unsigned long long)n_tier2);     // wave-steps that had to evaluate the back ring
+        atomicAdd(counters + 5, (unsigned long long)n_exact);     // wave-steps on the exact insertion path (last step, near-ties)
         if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
+#ifdef IFD_PROF
+        if (cloud == 0) {
+            atomicAdd(counters + 8, pc_build); atomicAdd(counters + 9, pc_eval); atomicAdd(counters + 10, pc_rep);
+            atomicAdd(counters + 11, pc_tiles); atomicAdd(counters + 12, pc_wait); atomicAdd(counters + 13, pc_adam);
+        }
+#endif
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
 #pragma unroll
@@ -1518,7 +1719,8 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void repulsion_kernel(const float* 
     __syncthreads();
     Top5 ta, tb;
     knn_scan2(X, K, pa, pb, ta, tb);
-    float la = 0.f, lb = 0.f, gca[3] = {0.f, 0.f, 0.f}, gcb[3] = {0.f, 0.f, 0.f};
+    float la = 0.f, lb = 0.f;
+    long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
     if (pa < K) rep_point(X, F, pa, ta, rc, la, gca, grad != nullptr);
     if (pb < K) rep_point(X, F, pb, tb, rc, lb, gcb, grad != nullptr);
     if (knn_idx != nullptr) {
@@ -1543,7 +1745,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void repulsion_kernel(const float* 
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
                     grad[((size_t)cloud * K + pt) * 3 + a] =
-                        ((q ? gcb[a] : gca[a]) + __ll2float_rn(F[3 * pt + a]) * FIX_INV) * sc;
+                        __ll2float_rn(F[3 * pt + a] + (q ? gcb[a] : gca[a])) * FIX_INV * sc;
         }
     }
 }
@@ -1565,7 +1767,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + MAXK * 3 * 8 + MAXK * STAGE_M * 2 + 128 * 4;   // 158,480 B
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + 16 + MAXK * 3 * 8 + MAXK * (4 + 4 + 1 + 1) + 128 * 4;   // 135,968 B
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;
 constexpr size_t NRM_LDS = MAXK * 16 + 64;

@@ -182,9 +182,11 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
 
 /* Diagnostics (no reference counterpart): counters of the most recent ifd_optimize on this context, copied
  * to HOST memory; synchronises the device.  [0] wave-level neighbour-list rebuilds, [1] wave-level certificate
- * failures served by the exact brute-force scan, [2] wave-level candidate-collection passes,
- * [3] shader-clock cycles cloud 0 spent in the optimiser kernel (effective clock = cycles / kernel time).  n <= IFD_N_COUNTERS. */
-#define IFD_N_COUNTERS 8
+ * failures served by the exact brute-force scan, [2] extra wave-level rebuild work (exact scans for the list
+ * radii + re-passes for overflowed balls), [3] shader-clock cycles cloud 0 spent in the optimiser kernel
+ * (effective clock = cycles / kernel time), [4] wave-steps that had to evaluate the back ring of the lists.
+ * n <= IFD_N_COUNTERS. */
+#define IFD_N_COUNTERS 16
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
 
 /* normalize_batch_pc (ConvONet/opt_defense.py:76-83) in place on p [B,K,3]. */
