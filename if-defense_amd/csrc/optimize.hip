@@ -1078,26 +1078,43 @@ __device__ __forceinline__ void keys6_insert(Keys6& q, unsigned int x) {
     q.k1 = umed3(q.k0, q.k1, x);
     q.k0 = min(q.k0, x);
 }
-template <int E0, int E1>
-__device__ __forceinline__ void list_keys6_2(const f32x4* __restrict__ X, const uint16_t* La, const uint16_t* Lb,
-                                             int ia, int ib, Keys6& qa, Keys6& qb) {
+// wa / wb: the LIST_M / 8 packed index words of the two lists (loaded by the caller in ONE global round trip);
+// chunks [C0, C1) of 8 entries are evaluated.  Per chunk all 16 coordinate reads are issued before the first use:
+// the phase is latency-bound (a lone VALU wave next to an MFMA wave), so LDS round trips are batched, not chained.
+template <int C0, int C1>
+__device__ __forceinline__ void list_keys6_2(const f32x4* __restrict__ X, const u32x4 (&wa)[LIST_M / 8],
+                                             const u32x4 (&wb)[LIST_M / 8], int ia, int ib, Keys6& qa, Keys6& qb) {
     const f32x4 xa = X[ia], xb = X[ib];
 #pragma unroll
-    for (int c = E0 / 8; c < E1 / 8; ++c) {
-        const u32x4 wa = reinterpret_cast<const u32x4*>(La)[c], wb = reinterpret_cast<const u32x4*>(Lb)[c];
+    for (int c = C0; c < C1; ++c) {
+        unsigned int ja[8], jb[8];
+        f32x4 pa_[8], pb_[8];
 #pragma unroll
         for (int e8 = 0; e8 < 8; ++e8) {
-            const unsigned int pka = wa[e8 >> 1], pkb = wb[e8 >> 1];
-            const unsigned int ja = (e8 & 1) ? (pka >> 16) : (pka & 0xffffu);
-            const unsigned int jb = (e8 & 1) ? (pkb >> 16) : (pkb & 0xffffu);
-            const f32x4 pa_ = X[ja], pb_ = X[jb];
-            const float ax = pa_.x - xa.x, ay = pa_.y - xa.y, az = pa_.z - xa.z;
-            const float bx = pb_.x - xb.x, by = pb_.y - xb.y, bz = pb_.z - xb.z;
+            const unsigned int pka = wa[c][e8 >> 1], pkb = wb[c][e8 >> 1];
+            ja[e8] = (e8 & 1) ? (pka >> 16) : (pka & 0xffffu);
+            jb[e8] = (e8 & 1) ? (pkb >> 16) : (pkb & 0xffffu);
+        }
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) { pa_[e8] = X[ja[e8]]; pb_[e8] = X[jb[e8]]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const float ax = pa_[e8].x - xa.x, ay = pa_[e8].y - xa.y, az = pa_[e8].z - xa.z;
+            const float bx = pb_[e8].x - xb.x, by = pb_[e8].y - xb.y, bz = pb_[e8].z - xb.z;
             const float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
             const float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
-            keys6_insert(qa, (__float_as_uint(da) & ~KEY_IDX_MASK) | ja);
-            keys6_insert(qb, (__float_as_uint(db) & ~KEY_IDX_MASK) | jb);
+            keys6_insert(qa, (__float_as_uint(da) & ~KEY_IDX_MASK) | ja[e8]);
+            keys6_insert(qb, (__float_as_uint(db) & ~KEY_IDX_MASK) | jb[e8]);
         }
+    }
+}
+__device__ __forceinline__ void load_list_words(const uint16_t* La, const uint16_t* Lb, u32x4 (&wa)[LIST_M / 8],
+                                                u32x4 (&wb)[LIST_M / 8]) {
+#pragma unroll
+    for (int c = 0; c < LIST_M / 8; ++c) {
+        wa[c] = reinterpret_cast<const u32x4*>(La)[c];
+        wb[c] = reinterpret_cast<const u32x4*>(Lb)[c];
     }
 }
 // upper bound of the squared distance of key k (INF for the init value / NaN patterns)
@@ -1119,16 +1136,56 @@ struct KnnPt {
     float rho_b;        // front + back hold every point that was within rho_b at build time
     float al_f, al_b;   // alpha^2 of the two radii: rho^2 = al * (upper bound of the squared 5-NN distance)
     f32x4 x0;           // position at build time
+    float dbase;        // Dmax at this point's build time (0 for whole-cloud rebuilds, which start a new epoch)
+    float r5p;          // last step's 5-NN distance (upper bound)
+    bool frag;          // certificate too short-lived to be worth a whole-cloud rebuild: refreshed individually
+    bool pend;          // individual refresh requested for the next step
 };
 
-// Wave-cooperative ("transposed") list build: the lanes hold the K candidate points in registers (16 each), the
-// wave walks over its 128 target points; for each target one distance per candidate, hits are compacted with
-// ballot / mbcnt into the target's list - no divergent branches, exact counts, one pass.  TF / TB (LDS) hold the
-// squared front / back radii per point, CF / CB (LDS) receive the hit counts (saturated at 255).
-__device__ __forceinline__ void knn_build_lists(const f32x4* __restrict__ X, int K, int wave, int lane,
-                                                uint16_t* __restrict__ lists, const float* __restrict__ TF,
-                                                const float* __restrict__ TB, uint8_t* __restrict__ CF,
-                                                uint8_t* __restrict__ CB, bool overflowed_only) {
+// One target of the wave-cooperative ("transposed") list build: the lanes hold the K candidate points in registers
+// (16 each); one distance per candidate, hits are compacted with ballot / mbcnt into the target's list - no divergent
+// branches, exact counts.  tf / tb: squared front / back radii (wave-uniform).  Unused slots get the dummy index.
+__device__ __forceinline__ void knn_build_one(const float (&cx)[16], const float (&cy)[16], const float (&cz)[16],
+                                              const f32x4 xi, int i, int lane, float tf, float tb,
+                                              uint16_t* __restrict__ lst, int& nf_out, int& nb_out) {
+    int nf = 0, nb = 0;                                                            // wave-uniform running counts
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = lane + 64 * k;
+        const float ex = cx[k] - xi.x, ey = cy[k] - xi.y, ez = cz[k] - xi.z;
+        const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+        const bool in_b = d < tb && j != i;
+        const bool in_f = d < tf && in_b;
+        const unsigned long long mf = __ballot(in_f);
+        const int pos_f = nf + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
+        const bool to_f = in_f && pos_f < LIST_F;
+        if (to_f) lst[pos_f] = (uint16_t)j;
+        nf += __popcll(mf);
+        const bool to_b = in_b && !to_f;                  // ring members + front hits that did not fit
+        const unsigned long long mb = __ballot(to_b);
+        const int pos_b = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+        if (to_b && pos_b < LIST_B) lst[LIST_F + pos_b] = (uint16_t)j;
+        nb += __popcll(mb);
+    }
+    // unused slots point at the dummy X[MAXK] (the key evaluation does not look at counts)
+    if (lane < LIST_M && lane >= (lane < LIST_F ? nf : LIST_F + nb)) lst[lane] = (uint16_t)MAXK;
+    nf_out = nf;
+    nb_out = nb;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// (Re)build the lists of the flagged points of this wave (need_a / need_b per lane; d4a / d4b: upper bounds of their
+// squared 5-NN distances at the current positions).  Targets are taken one at a time off the ballot mask, so the
+// cost is ~1 us for loading the candidates plus ~0.5 us per target - whole-cloud rebuilds (all flagged) and the
+// individual refreshes of short-lived ("fragile") certificates share this code.  A ball that overflows its list is
+// shrunk in proportion to the overshoot (hit count ~ r^2 on a surface) and rebuilt on the spot.
+__device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, int wave, int lane,
+                                            uint16_t* __restrict__ lists, bool need_a, bool need_b, float d4a,
+                                            float d4b, KnnPt& ka, KnnPt& kb, float dbase, float mv,
+                                            unsigned int& n_targets, unsigned int& n_repass) {
     float cx[16], cy[16], cz[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -1137,36 +1194,54 @@ __device__ __forceinline__ void knn_build_lists(const f32x4* __restrict__ X, int
         const bool v = j < K;
         cx[k] = v ? p.x : 1e18f; cy[k] = v ? p.y : 1e18f; cz[k] = v ? p.z : 1e18f;
     }
-#pragma unroll 1
-    for (int ii = 0; ii < 128; ++ii) {
-        const int i = ((ii & 64) ? OPT_THREADS : 0) + wave * 64 + (ii & 63);     // the points this wave's lanes own
-        if (i >= K) continue;                                                      // wave-uniform
-        if (overflowed_only && CF[i] <= LIST_F && CB[i] <= LIST_B) continue;       // wave-uniform (LDS broadcast)
-        const f32x4 xi = X[i];
-        const float tf = TF[i], tb = TB[i];
-        uint16_t* lst = lists + (size_t)i * LIST_M;
-        int nf = 0, nb = 0;                                                        // wave-uniform running counts
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = lane + 64 * k;
-            const float ex = cx[k] - xi.x, ey = cy[k] - xi.y, ez = cz[k] - xi.z;
-            const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-            const bool in_b = d < tb && j != i;
-            const bool in_f = d < tf && in_b;
-            const unsigned long long mf = __ballot(in_f);
-            int pos_f = nf + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
-            const bool to_f = in_f && pos_f < LIST_F;
-            if (to_f) lst[pos_f] = (uint16_t)j;
-            nf += __popcll(mf);
-            const bool to_b = in_b && !to_f;                  // ring members + front hits that did not fit
-            const unsigned long long mb = __ballot(to_b);
-            const int pos_b = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
-            if (to_b && pos_b < LIST_B) lst[LIST_F + pos_b] = (uint16_t)j;
-            nb += __popcll(mb);
+    for (int half = 0; half < 2; ++half) {
+        KnnPt& kp = half ? kb : ka;
+        const float d4 = half ? d4b : d4a;
+        const float my_tf = d4 * kp.al_f, my_tb = d4 * kp.al_b;
+        unsigned long long mask = __ballot(half ? need_b : need_a);
+#pragma unroll 1
+        while (mask != 0ull) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int i = (half ? OPT_THREADS : 0) + wave * 64 + l;
+            float tf = readlane_f(my_tf, l), tb = readlane_f(my_tb, l);
+            const f32x4 xi = X[i];                                                   // wave-uniform address
+            uint16_t* lst = lists + (size_t)i * LIST_M;
+            int nf, nb;
+            ++n_targets;
+#pragma unroll 1
+            for (int rep = 0;; ++rep) {
+                knn_build_one(cx, cy, cz, xi, i, lane, tf, tb, lst, nf, nb);
+                if ((nf <= LIST_F && nb <= LIST_B) || rep == 3) break;
+                ++n_repass;
+                const float n_in = (float)(min(nf, LIST_F) + nb);                   // points inside the back radius
+                float nf_new = (float)nf;
+                if (nf > LIST_F) { tf *= (0.7f * LIST_F) / (float)nf; nf_new = 0.7f * LIST_F; }
+                if (n_in - nf_new > 0.85f * LIST_B) tb *= (nf_new + 0.75f * LIST_B) / n_in;
+                tb = fmaxf(tb, tf);
+            }
+            if (lane == l) {
+                kp.cnt_f = min(nf, LIST_F);
+                kp.rho_f = nf <= LIST_F ? sqrtf(tf) : 0.f;          // front complete only if everything fitted
+                kp.cnt_b = nb <= LIST_B ? nb : -1;
+                kp.rho_b = sqrtf(tb);
+                // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly when sparse
+                if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb / d4; }
+                if (nf < LIST_F / 2) kp.al_f *= 1.15f;
+                if (nf + nb < LIST_M / 2) kp.al_b *= 1.15f;
+                kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
+                kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
+                kp.al_f = fminf(kp.al_f, kp.al_b);
+                kp.x0 = xi;
+                kp.dbase = dbase;
+                // expected lifetime of the certificate ~ (rho - r5 - 6 mv) / (~2 mv per step)
+#ifndef IFD_FRAG_MULT
+#define IFD_FRAG_MULT 16.f
+#endif
+                kp.frag = kp.rho_b - sqrtf(d4) < IFD_FRAG_MULT * mv;
+            }
         }
-        // unused slots point at the dummy X[MAXK] (the key evaluation does not look at counts)
-        if (lane < LIST_M && lane >= (lane < LIST_F ? nf : LIST_F + nb)) lst[lane] = (uint16_t)MAXK;
-        if (lane == 0) { CF[i] = (uint8_t)min(nf, 255); CB[i] = (uint8_t)min(nb, 255); }
     }
 }
 
@@ -1290,11 +1365,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
     f32x4* X = G + MAXK;                                             // current points; X[MAXK] = far-away dummy
     long long* F = reinterpret_cast<long long*>(X + MAXK + 1);       // fixed-point neighbour-gradient scatter
-    float* TF = reinterpret_cast<float*>(F + 3 * MAXK);              // squared front radius per point (list builds)
-    float* TB = TF + MAXK;                                           // squared back radius per point
-    uint8_t* CF = reinterpret_cast<uint8_t*>(TB + MAXK);             // hit counts written by the build
-    uint8_t* CB = CF + MAXK;
-    float* scratch = reinterpret_cast<float*>(CB + MAXK);            // 128 floats
+    float* scratch = reinterpret_cast<float*>(F + 3 * MAXK);         // 128 floats
 
     const int cloud = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1337,14 +1408,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     // certified neighbour lists of the two owned points
     uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;   // global (L2-resident)
     uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + (pb & (MAXK - 1))) * LIST_M;
-    KnnPt ka = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}};    // ~10 front / ~35 total hits on a flat patch
+    KnnPt ka = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false};   // ~10 front / ~35 total hits on a flat patch
     KnnPt kb = ka;
     uint16_t* cloud_lists = knn_lists + (size_t)cloud * MAXK * LIST_M;
     float* dmaxbuf = scratch + 32;                                   // [2][MAX_WAVES] per-wave max |x - x0| (next step)
     float* movebuf = scratch + 64;                                   // [2][MAX_WAVES] per-wave max single-step move
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
     int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
-    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0, n_tier2 = 0, n_exact = 0;
+    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0, n_tier2 = 0, n_exact = 0, n_refresh = 0, n_targets = 0;
 #ifdef IFD_PROF      // cycle accounting of cloud 0 (diagnostic builds only; overwrites the counters)
     unsigned long long pc_build = 0, pc_eval = 0, pc_rep = 0, pc_tiles = 0, pc_wait = 0, pc_adam = 0, pc_t = 0;
 #define PROF_T0() pc_t = __builtin_readcyclecounter()
@@ -1385,83 +1456,43 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                     // the certificate must survive one more step: r5 grows <= 2 mv, both displacements <= mv
                     const float soft_slack = 6.f * mv;
                     PROF_T0();
-                    if (force) {
-                        // ---- synchronous rebuild (every owner wave, this step) ------------------------------------
-                        ++n_rebuild;
-                        // upper bounds of the squared 5-NN distances: any 5 members of the current lists at their
-                        // present positions (a truncated back segment still holds valid points), else the exact scan
-                        bool have = step != 0;
-                        if (have) {
-                            Keys6 qa, qb;
-                            keys6_init(qa);
-                            keys6_init(qb);
-                            list_keys6_2<0, LIST_M>(X, La, Lb, ia, ib, qa, qb);
-                            ta.d4 = key_d_upper(qa.k4);
-                            tb.d4 = key_d_upper(qb.k4);
-                            have = ta.d4 < 1e30f && tb.d4 < 1e30f;       // the dummy point is ~3e36 away
-                        }
-                        if (!__all(have)) {
-                            ++n_pass;
-                            knn_scan2(X, K, pa, pb, ta, tb);
-                        }
-                        if (pa < K) { TF[pa] = ta.d4 * ka.al_f; TB[pa] = ta.d4 * ka.al_b; }
-                        if (pb < K) { TF[pb] = tb.d4 * kb.al_f; TB[pb] = tb.d4 * kb.al_b; }
-                        __builtin_amdgcn_wave_barrier();          // this wave's lanes wrote, this wave reads (LDS is in order)
-                        knn_build_lists(X, K, wave, lane, cloud_lists, TF, TB, CF, CB, false);
-                        __builtin_amdgcn_wave_barrier();
-                        // overflowed balls: shrink the radius in proportion to the overshoot (hit count ~ r^2 on a
-                        // surface) and rebuild just those points; whatever still overflows is served by the scan
-#pragma unroll 1
-                        for (int rep = 0; rep < 3; ++rep) {
-                            bool redo = false;
-#pragma unroll
-                            for (int qq = 0; qq < 2; ++qq) {
-                                const int pt = qq ? pb : pa;
-                                if (pt < K) {
-                                    const int nf = CF[pt], nb = CB[pt];
-                                    if (nf > LIST_F || nb > LIST_B) {
-                                        float tf = TF[pt], tb2 = TB[pt];
-                                        const float n_in = (float)(min(nf, LIST_F) + nb);       // points inside the back radius
-                                        float nf_new = (float)nf;
-                                        if (nf > LIST_F) { tf *= (0.7f * LIST_F) / (float)nf; nf_new = 0.7f * LIST_F; }
-                                        if (n_in - nf_new > 0.85f * LIST_B) tb2 *= (nf_new + 0.75f * LIST_B) / n_in;
-                                        tb2 = fmaxf(tb2, tf);
-                                        TF[pt] = tf; TB[pt] = tb2;
-                                        redo = true;
-                                    }
-                                }
+                    const bool need_a = pa < K && (force || ka.pend), need_b = pb < K && (force || kb.pend);
+                    if (__any(need_a || need_b)) {
+                        float d4a, d4b;        // upper bounds of the squared 5-NN distances at the current positions
+                        if (force) {
+                            // ---- synchronous whole-cloud rebuild (every owner wave, this step): new epoch ---------
+                            ++n_rebuild;
+                            // any 5 members of the current lists (a truncated ring still holds valid points), else scan
+                            bool have = step != 0;
+                            if (have) {
+                                Keys6 qa, qb;
+                                keys6_init(qa);
+                                keys6_init(qb);
+                                u32x4 wa[LIST_M / 8], wb[LIST_M / 8];
+                                load_list_words(La, Lb, wa, wb);
+                                list_keys6_2<0, LIST_M / 8>(X, wa, wb, ia, ib, qa, qb);
+                                ta.d4 = key_d_upper(qa.k4);
+                                tb.d4 = key_d_upper(qb.k4);
+                                have = ta.d4 < 1e30f && tb.d4 < 1e30f;       // the dummy point is ~3e36 away
                             }
-                            if (!__any(redo)) break;
-                            ++n_pass;
-                            __builtin_amdgcn_wave_barrier();
-                            knn_build_lists(X, K, wave, lane, cloud_lists, TF, TB, CF, CB, true);
-                            __builtin_amdgcn_wave_barrier();
-                        }
-#pragma unroll
-                        for (int qq = 0; qq < 2; ++qq) {
-                            KnnPt& kp = qq ? kb : ka;
-                            const int pt = qq ? pb : pa;
-                            const float d4 = qq ? tb.d4 : ta.d4;
-                            if (pt < K) {
-                                const int nf = CF[pt], nb = CB[pt];
-                                const float tf = TF[pt], tb2 = TB[pt];
-                                kp.cnt_f = min(nf, LIST_F);
-                                kp.rho_f = nf <= LIST_F ? sqrtf(tf) : 0.f;          // front complete only if everything fitted
-                                kp.cnt_b = nb <= LIST_B ? nb : -1;
-                                kp.rho_b = sqrtf(tb2);
-                                // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly
-                                // when sparsely filled
-                                if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb2 / d4; }
-                                if (nf < LIST_F / 2) kp.al_f *= 1.15f;
-                                if (nf + nb < LIST_M / 2) kp.al_b *= 1.15f;
-                                kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
-                                kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
-                                kp.al_f = fminf(kp.al_f, kp.al_b);
-                                kp.x0 = X[pt];
+                            if (!__all(have)) {
+                                ++n_pass;
+                                knn_scan2(X, K, pa, pb, ta, tb);
                             }
+                            d4a = ta.d4;
+                            d4b = tb.d4;
+                            dmax = 0.f;
+                        } else {
+                            // ---- individual refresh of fragile certificates: r5 grows by at most 2 mv per step ----
+                            ++n_refresh;
+                            const float ra = ka.r5p + 2.f * mv, rb = kb.r5p + 2.f * mv;
+                            d4a = ra * ra;
+                            d4b = rb * rb;
                         }
-                        dmax = 0.f;
+                        knn_refresh(X, K, wave, lane, cloud_lists, need_a, need_b, d4a, d4b, ka, kb, dmax, mv,
+                                    n_targets, n_pass);
                     }
+                    ka.pend = kb.pend = false;
                     PROF_ACC(pc_build);
                     // ---- tier 1: the front ball -----------------------------------------------------------------
                     const f32x4 xa = X[ia], xb = X[ib];
@@ -1469,33 +1500,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                                             (xa.z - ka.x0.z) * (xa.z - ka.x0.z));
                     const float db0 = sqrtf((xb.x - kb.x0.x) * (xb.x - kb.x0.x) + (xb.y - kb.x0.y) * (xb.y - kb.x0.y) +
                                             (xb.z - kb.x0.z) * (xb.z - kb.x0.z));
+                    // displacement budget already spent: own move since the build + everybody else's (since the epoch
+                    // reference: now, and at this point's build time).  A list built THIS step is exact as it stands.
+                    const float spent_a = da0 + dmax + ka.dbase, spent_b = db0 + dmax + kb.dbase;
+                    const float hs_a = need_a ? 0.f : spent_a, hs_b = need_b ? 0.f : spent_b;
                     bool exact = last;       // the reported loss sums the five terms in ascending-distance order
-                    bool soft_ok = true;
+                    bool soft_a = true, soft_b = true;
                     if (!exact) {
                         // ---- fast path: key networks (see list_keys6_2) ------------------------------------------
                         Keys6 qa, qb;
                         keys6_init(qa);
                         keys6_init(qb);
-                        list_keys6_2<0, LIST_F>(X, La, Lb, ia, ib, qa, qb);
+                        u32x4 wa[LIST_M / 8], wb[LIST_M / 8];
+                        load_list_words(La, Lb, wa, wb);       // front and ring together: one L2 round trip
+                        list_keys6_2<0, LIST_F / 8>(X, wa, wb, ia, ib, qa, qb);
                         float r5a = sqrtf(key_d_upper(qa.k4)), r5b = sqrtf(key_d_upper(qb.k4));
-                        const bool ok1 = (pa >= K || r5a < (ka.rho_f - da0 - dmax) * 0.99999f - 1e-7f) &&
-                                         (pb >= K || r5b < (kb.rho_f - db0 - dmax) * 0.99999f - 1e-7f);
+                        // every point outside a ball of build radius rho is now farther than rho - (spent budget)
+                        const bool ok1 = (pa >= K || r5a < (ka.rho_f - hs_a) * 0.99999f - 1e-7f) &&
+                                         (pb >= K || r5b < (kb.rho_f - hs_b) * 0.99999f - 1e-7f);
                         bool scanned = false;
                         if (!__all(ok1)) {
                             ++n_tier2;
-                            list_keys6_2<LIST_F, LIST_M>(X, La, Lb, ia, ib, qa, qb);
+                            list_keys6_2<LIST_F / 8, LIST_M / 8>(X, wa, wb, ia, ib, qa, qb);
                             r5a = sqrtf(key_d_upper(qa.k4));
                             r5b = sqrtf(key_d_upper(qb.k4));
-                            const float bnd_a = (ka.rho_b - da0 - dmax) * 0.99999f - 1e-7f;
-                            const float bnd_b = (kb.rho_b - db0 - dmax) * 0.99999f - 1e-7f;
-                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < bnd_a)) && (pb >= K || (kb.cnt_b >= 0 && r5b < bnd_b));
+                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f)) &&
+                                              (pb >= K || (kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f));
                             if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
                                 ++n_brute;
                                 knn_scan2(X, K, pa, pb, ta, tb);
                                 scanned = true;
                             }
-                            soft_ok = (pa >= K || ka.cnt_b < 0 || r5a < bnd_a - soft_slack) &&
-                                      (pb >= K || kb.cnt_b < 0 || r5b < bnd_b - soft_slack);
+                            // will it still hold next step?  (crowded balls, cnt_b < 0, are served by the scan anyway)
+                            soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
+                            soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
                         }
                         if (!scanned) {
                             const bool amb = (pa < K && keys6_ambiguous(qa)) || (pb < K && keys6_ambiguous(qb));
@@ -1510,29 +1548,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                     if (exact) {
                         // ---- exact path: sorted insertion with indices (last step, near-ties) --------------------
                         ++n_exact;
-                        soft_ok = true;
+                        soft_a = soft_b = true;
                         top5_init(ta);
                         top5_init(tb);
                         list_top5_2<0, LIST_F>(X, La, Lb, ka.cnt_f, kb.cnt_f, ia, ib, ta, tb);
-                        // every point outside a ball of build radius rho is now farther than rho - (both displacements)
-                        const bool ok1 = (pa >= K || sqrtf(ta.d4) < (ka.rho_f - da0 - dmax) * 0.99999f - 1e-7f) &&
-                                         (pb >= K || sqrtf(tb.d4) < (kb.rho_f - db0 - dmax) * 0.99999f - 1e-7f);
+                        const bool ok1 = (pa >= K || sqrtf(ta.d4) < (ka.rho_f - hs_a) * 0.99999f - 1e-7f) &&
+                                         (pb >= K || sqrtf(tb.d4) < (kb.rho_f - hs_b) * 0.99999f - 1e-7f);
                         if (!__all(ok1)) {
-                            // ---- tier 2: add the ring -----------------------------------------------------------------
                             list_top5_2<LIST_F, LIST_M>(X, La, Lb, LIST_F + ka.cnt_b, LIST_F + kb.cnt_b, ia, ib, ta, tb);
-                            const float bnd_a = (ka.rho_b - da0 - dmax) * 0.99999f - 1e-7f;
-                            const float bnd_b = (kb.rho_b - db0 - dmax) * 0.99999f - 1e-7f;
                             const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
-                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < bnd_a)) && (pb >= K || (kb.cnt_b >= 0 && r5b < bnd_b));
-                            if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
+                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f)) &&
+                                              (pb >= K || (kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f));
+                            if (!__all(hard)) {
                                 ++n_brute;
                                 knn_scan2(X, K, pa, pb, ta, tb);
                             }
-                            // crowded balls (cnt_b < 0) can only be served by the scan; they do not ask for rebuilds
-                            soft_ok = (pa >= K || ka.cnt_b < 0 || r5a < bnd_a - soft_slack) &&
-                                      (pb >= K || kb.cnt_b < 0 || r5b < bnd_b - soft_slack);
+                            soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
+                            soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
                         }
                     }
+                    ka.r5p = sqrtf(ta.d4);
+                    kb.r5p = sqrtf(tb.d4);
+                    // a certificate about to expire: fragile ones are refreshed individually next step, the others
+                    // mean the epoch is old -> whole-cloud rebuild next step
+                    ka.pend = !soft_a && ka.frag;
+                    kb.pend = !soft_b && kb.frag;
+                    const bool soft_ok = (soft_a || ka.frag) && (soft_b || kb.frag);
                     if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
                     PROF_ACC(pc_eval);
                 }
@@ -1620,7 +1661,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 const f32x4 x0 = q ? kb.x0 : ka.x0;
                 const float dsq = (xs[0] - x0.x) * (xs[0] - x0.x) + (xs[1] - x0.y) * (xs[1] - x0.y) +
                                   (xs[2] - x0.z) * (xs[2] - x0.z);
-                dmax2 = fmaxf(dmax2, dsq);
+                dmax2 = fmaxf(dmax2, sqrtf(dsq) + (q ? kb.dbase : ka.dbase));
                 mv2 = fmaxf(mv2, msq);
                 X[pt] = f32x4{xs[0], xs[1], xs[2], 0.f};
             }
@@ -1628,7 +1669,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         dmax2 = wave_max(dmax2);
         mv2 = wave_max(mv2);
         if (lane == 0) {
-            dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(dmax2) * 1.00001f + 1e-7f;
+            dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = dmax2 * 1.00001f + 1e-7f;
             movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
         }
         if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
@@ -1642,8 +1683,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         atomicAdd(counters + 2, (unsigned long long)n_pass);      // extra rebuild work: exact scans for radii + overflow re-passes
         atomicAdd(counters + 4, (unsigned long long)n_tier2);     // wave-steps that had to evaluate the back ring
         atomicAdd(counters + 5, (unsigned long long)n_exact);     // wave-steps on the exact insertion path (last step, near-ties)
+        atomicAdd(counters + 6, (unsigned long long)n_refresh);   // wave-steps with individual list refreshes
+        atomicAdd(counters + 7, (unsigned long long)n_targets);   // lists built (whole-cloud rebuilds + individual refreshes)
         if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
 #ifdef IFD_PROF
+        if (tid == 0) {
+            const unsigned long long cyc = __builtin_readcyclecounter() - t_begin;
+            atomicMax(counters + 14, cyc);
+            atomicMax(counters + 13, (unsigned long long)n_rebuild << 32);
+            atomicAdd(counters + 15, cyc);
+        }
         if (cloud == 0) {
             atomicAdd(counters + 8, pc_build); atomicAdd(counters + 9, pc_eval); atomicAdd(counters + 10, pc_rep);
             atomicAdd(counters + 11, pc_tiles); atomicAdd(counters + 12, pc_wait); atomicAdd(counters + 13, pc_adam);
@@ -1767,7 +1816,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + 16 + MAXK * 3 * 8 + MAXK * (4 + 4 + 1 + 1) + 128 * 4;   // 135,968 B
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + 16 + MAXK * 3 * 8 + 128 * 4;   // 125,728 B
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;
 constexpr size_t NRM_LDS = MAXK * 16 + 64;

@@ -233,8 +233,8 @@ class Restorer:
         buf = (C.c_uint64 * 16)()
         self._check(self.lib.ifd_get_counters(self.ctx, buf, 16))
         return {"knn_rebuilds": int(buf[0]), "knn_brute_scans": int(buf[1]), "knn_passes": int(buf[2]),
-                "cloud0_shader_cycles": int(buf[3]), "knn_ring_evals": int(buf[4]),
-                "prof_cycles": [int(buf[i]) for i in range(8, 14)]}      # only in -DIFD_PROF diagnostic builds
+                "cloud0_shader_cycles": int(buf[3]), "knn_ring_evals": int(buf[4]), "knn_exact_evals": int(buf[5]), "knn_refresh_waves": int(buf[6]), "knn_lists_built": int(buf[7]),
+                "prof_cycles": [int(buf[i]) for i in range(8, 16)]}      # only in -DIFD_PROF diagnostic builds
 
     def normalize_batch_pc(self, points: torch.Tensor) -> torch.Tensor:
         """normalize_batch_pc (opt_defense.py:76-83); returns a new tensor."""

@@ -26,3 +26,8 @@ for rw in (500.0, 0.0, 500.0):
         names = ("build", "eval", "rep", "tiles", "wait", "adam")
         print("   cloud 0, mean over 8 waves, %% of kernel cycles: " +
               "  ".join("%s %.1f" % (nm, 100.0 * v / 8 / tot) for nm, v in zip(names, c["prof_cycles"])))
+        print("   cycles/step: cloud0 %.0f  mean cloud %.0f  max cloud %.0f   (launch wall per round-step at 2.3 GHz: %.0f)" %
+              (tot / 501, c["prof_cycles"][7] / n / 501, c["prof_cycles"][6] / 501, dt * 2.3e9 / 501 / rounds))
+        print("   max rebuilds in a cloud %d" % (c["prof_cycles"][5] >> 32))
+    print("   refresh wave-steps/wave-step %.3f, lists built per cloud-step %.1f, exact evals/wave-step %.4f" %
+          (c["knn_refresh_waves"] / (8.0 * n * 501), c["knn_lists_built"] / (n * 501.0), c["knn_exact_evals"] / (8.0 * n * 501)))
