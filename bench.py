@@ -74,6 +74,44 @@ def synth_clouds(n, seed=1234):
     return out
 
 
+def _renorm(p):
+    p = p - p.mean(0)
+    return (p / np.linalg.norm(p, axis=1).max()).astype(np.float32)
+
+
+def knn_attack_like(clouds, seed=1234):
+    """BASELINE config #3: every point displaced by U(-0.02, 0.02)^3, 5 % of the points pulled into
+    3 tight clusters (sigma 0.01), re-normalised.  Parity-test input, not a bench line."""
+    rng = np.random.default_rng(seed + 3)
+    out = np.empty_like(clouds)
+    for i, c in enumerate(clouds):
+        p = c.astype(np.float64) + rng.uniform(-0.02, 0.02, c.shape)
+        k = len(p)
+        moved = rng.choice(k, k // 20, replace=False)
+        centres = p[rng.choice(k, 3, replace=False)]
+        p[moved] = centres[rng.integers(0, 3, len(moved))] + rng.normal(0.0, 0.01, (len(moved), 3))
+        out[i] = _renorm(p)
+    return out
+
+
+def drop_like(clouds, n_drop=200, seed=1234):
+    """BASELINE config #5(i): delete the n_drop points nearest a random anchor (what untargeted_drop_attack.py
+    --num_drop=200 emits: [N, K - n_drop, 3])."""
+    rng = np.random.default_rng(seed + 5)
+    out = np.empty((len(clouds), clouds.shape[1] - n_drop, 3), np.float32)
+    for i, c in enumerate(clouds):
+        anchor = c[rng.integers(0, len(c))]
+        keep = np.sort(np.argsort(((c - anchor) ** 2).sum(1))[n_drop:])
+        out[i] = c[keep]
+    return out
+
+
+def subsample_like(clouds, k=256, seed=1234):
+    """BASELINE config #5(ii): K = 256 random subsample of every cloud (sparse input -> 1024 restored points)."""
+    rng = np.random.default_rng(seed + 6)
+    return np.stack([c[np.sort(rng.choice(len(c), k, replace=False))] for c in clouds]).astype(np.float32)
+
+
 def cpu_baseline(clouds, n_sample=16, budget_s=15.0):
     """The CPU oracle (a port of the reference's op sequence: bmm-kNN + topk, autograd, torch.optim.Adam) timed
     on the host cores on a bounded sample, scaled to 501 steps.  Reported next to the GPU number, not a target.

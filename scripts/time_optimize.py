@@ -8,7 +8,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ifdefense_amd as I  # noqa: E402
-from oracle.convonet_oracle import make_random_weights  # noqa: E402  (weights only)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--clouds", type=int, default=512)
@@ -17,7 +16,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--rep_weight", type=float, default=500.0)
 a = ap.parse_args()
 
-r = I.Restorer(I.weights.pack_state_dict(make_random_weights(0)), device="cuda:0")
+r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device="cuda:0")
 g = torch.Generator().manual_seed(0)
 B = a.clouds
 v = torch.randn(B, 1024, 3, generator=g)
