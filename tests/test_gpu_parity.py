@@ -420,6 +420,41 @@ def test_cli_end_to_end(tmp_path, np_weights):
     np.testing.assert_allclose(np.linalg.norm(z["test_pc"], axis=-1).max(axis=1), 1.0, rtol=1e-6)
 
 
+def _chamfer(a, b):
+    d = torch.cdist(torch.from_numpy(a), torch.from_numpy(b))
+    return float(d.min(1).values.mean() + d.min(0).values.mean())
+
+
+def test_p3_full_501_steps_against_oracle(restorer, golden, oracle_weights, planes2):
+    """Protocol P3: the 501-step trajectory is chaotic, so compare what is comparable - the share of
+    points within 1e-3 next to the oracle's own 1-ulp self-divergence, the final losses, and the symmetric Chamfer
+    distance build<->oracle against oracle<->perturbed oracle."""
+    from oracle import convonet_oracle as O
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    init = torch.from_numpy(golden["init_points"][:2])
+    ref, snaps = O.optimize_points(oracle_weights, init, planes2, rep_weight=500.0, iterations=500, normalize=False,
+                                   record=(500,))
+    bumped = torch.nextafter(init, torch.full_like(init, 2.0))                     # +1 ulp on every coordinate
+    ref2 = O.optimize_points(oracle_weights, bumped, planes2, rep_weight=500.0, iterations=500, normalize=False)
+    got, loss = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=500, normalize=False, return_loss=True)
+    got = got.cpu()
+    d_build = (got - ref).norm(dim=-1).numpy()
+    d_self = (ref2 - ref).norm(dim=-1).numpy()
+    cd_build = np.mean([_chamfer(got[b].numpy(), ref[b].numpy()) for b in range(2)])
+    cd_self = np.mean([_chamfer(ref2[b].numpy(), ref[b].numpy()) for b in range(2)])
+    print("P3 501 steps: within 1e-3: build %.3f (mean %.2e) | oracle self-divergence %.3f (mean %.2e); "
+          "Chamfer build<->oracle %.3e, oracle<->perturbed %.3e" %
+          ((d_build < 1e-3).mean(), d_build.mean(), (d_self < 1e-3).mean(), d_self.mean(), cd_build, cd_self))
+    assert (d_build < 1e-3).mean() > 0.8 * (d_self < 1e-3).mean() - 0.05
+    assert cd_build < 1.5 * cd_self + 1e-4
+    # final losses (evaluated at the pre-update points of the last step) within 1 %
+    with torch.no_grad():
+        _, occ, rep, _ = O.losses(oracle_weights, snaps[500], planes2, 500.0)
+    loss = loss.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(loss[:, 0].sum() / 2, float(occ), rtol=1e-2)
+    np.testing.assert_allclose(loss[:, 1].mean() * 500.0, float(rep), rtol=1e-2)
+
+
 def test_full_size_properties(restorer):
     """BASELINE size (2468 clouds x 1024 points x 501 steps): size-independent properties."""
     import sys, os
