@@ -1,0 +1,63 @@
+"""Reduce the rocprofv3 output of scripts/collect_profiles.sh to the small files committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def find(sub, pat):
+    fs = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return fs[0] if fs else None
+
+
+res = {}
+f = find("stats", "*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(out, "%s_bench_kernel_stats.csv" % tag), "w") as o:
+        o.write(open(f).read())
+    for r in rows:
+        if "optimize_kernel" in r["Name"]:
+            res["optimize_kernel_calls"] = int(r["Calls"])
+            res["optimize_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
+            res["optimize_kernel_share_pct"] = float(r["Percentage"])
+
+
+def pmc(sub):
+    f = find(sub, "*counter_collection.csv")
+    acc = {}
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "optimize_kernel" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        keep = [r for r in csv.DictReader(open(f)) if "optimize_kernel" in r["Kernel_Name"]]
+        if keep:
+            with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, sub)), "w", newline="") as o:
+                w = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
+                w.writeheader()
+                w.writerows(keep)
+    return acc
+
+
+fetch, write, tcc = pmc("fetch"), pmc("write"), pmc("tcc")
+if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
+    rd = 2.0 * fetch["FETCH_SIZE"] * 1024.0      # gfx950: 128-B requests of 16-B/lane loads tallied at 64 B
+    wr = write["WRITE_SIZE"] * 1024.0
+    res.update({
+        "command": "scripts/collect_profiles.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum, "
+                   "separate passes over python bench.py --steps 1 --warmup 0 --no-cpu-baseline)" % tag,
+        "kernel": "ifd::optimize_kernel, one launch = 2468 clouds x 1024 points x 501 Adam steps",
+        "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
+        "correction": "gfx950: FETCH_SIZE tallies 128-B requests of 16-B/lane loads at 64 B (MI355X_MICROARCH.md, HBM "
+                      "section) -> read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE taken at face value",
+        "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+        "optimize_kernel_hbm_bytes_per_launch": rd + wr, "per_cloud_bytes": (rd + wr) / 2468.0,
+        "algorithmic_gather_bytes_per_cloud": 788004864,
+    })
+    if "TCC_HIT_sum" in tcc:
+        res["L2_hit_rate"] = tcc["TCC_HIT_sum"] / (tcc["TCC_HIT_sum"] + tcc["TCC_MISS_sum"])
+json.dump(res, open(os.path.join(out, "roofline_traffic.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
