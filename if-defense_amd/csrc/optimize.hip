@@ -25,11 +25,11 @@
 //   transposed.  Weights stream from LDS as the A operand (one ds_read_b32 per MFMA, see ifd_device.h).
 #include "ifd_device.h"
 #include "ifd_internal.h"
+#include "knn_device.h"
 
 namespace ifd {
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct Acc2 {
     f32x4 t[2];     // M-tile 0 (channels 4q..4q+3) and M-tile 1 (channels 16+4q..)
@@ -942,410 +942,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 5-NN + repulsion
-// ---------------------------------------------------------------------------------------------
-struct Top5 {
-    float d0, d1, d2, d3, d4;
-    int i0, i1, i2, i3, i4;
-};
-
-__device__ __forceinline__ void top5_init(Top5& t) {
-    t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
-    t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
-}
-
-// Branch-free sorted insertion (bubble the new key down with selects).  NOTE: the obvious nested-ternary
-// form is turned into exec-mask control flow by hipcc (4x the code, I-cache thrash) - keep this shape.
-__device__ __forceinline__ void top5_insert_nb(Top5& t, float d, int j) {
-    bool c; float lo; int li;
-    c = d < t.d0; lo = c ? d : t.d0; li = c ? j : t.i0; d = c ? t.d0 : d; j = c ? t.i0 : j; t.d0 = lo; t.i0 = li;
-    c = d < t.d1; lo = c ? d : t.d1; li = c ? j : t.i1; d = c ? t.d1 : d; j = c ? t.i1 : j; t.d1 = lo; t.i1 = li;
-    c = d < t.d2; lo = c ? d : t.d2; li = c ? j : t.i2; d = c ? t.d2 : d; j = c ? t.i2 : j; t.d2 = lo; t.i2 = li;
-    c = d < t.d3; lo = c ? d : t.d3; li = c ? j : t.i3; d = c ? t.d3 : d; j = c ? t.i3 : j; t.d3 = lo; t.i3 = li;
-    c = d < t.d4; t.d4 = c ? d : t.d4; t.i4 = c ? j : t.i4;
-}
-
-__device__ __forceinline__ void top5_insert(Top5& t, float d, int j) {
-    if (d < t.d4) top5_insert_nb(t, d, j);      // rare after the first few dozen candidates
-}
-
-// Exact brute-force scan of all K points (broadcast LDS reads) for the two points of this thread
-// (self excluded by index).
-__device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, int pa, int pb, Top5& ta, Top5& tb) {
-    const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
-    top5_init(ta);
-    top5_init(tb);
-#pragma unroll 4
-    for (int j = 0; j < K; ++j) {
-        const f32x4 xj = X[j];
-        const float ax = xj.x - xa.x, ay = xj.y - xa.y, az = xj.z - xa.z;
-        const float bx = xj.x - xb.x, by = xj.y - xb.y, bz = xj.z - xb.z;
-        float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
-        float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
-        da = (j == pa) ? INFINITY : da;
-        db = (j == pb) ? INFINITY : db;
-        top5_insert(ta, da, j);
-        top5_insert(tb, db, j);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Certified neighbour lists: exact 5-NN at O(LIST_M) per point per step.
-//
-//   build (rare, all waves of the cloud in the same step):  for each point i store every j with
-//       |x_j - x_i| < rho_i, rho_i^2 = alpha2_i * (an upper bound of i's squared 5-NN distance); alpha2_i
-//       adapts so that the ball holds <= LIST_M points.  x0_i = x_i at build time.
-//   step:  the 5 nearest list members are the true 5-NN iff  r5 < rho_i - |x_i - x0_i| - Dmax, with
-//       Dmax = max_j |x_j - x0_j|  (a point outside the list was >= rho_i away at build time).
-//       soft margin violated -> request a synchronous rebuild for the NEXT step (nobody stalls alone);
-//       certificate violated -> this wave runs the exact brute-force scan for this step.
-//   Either way every step uses the exact 5-NN set; ties follow ascending j like the scan.
-// ---------------------------------------------------------------------------------------------
-constexpr int LIST_F = 16;               // "front": every point within rho_f at build time (evaluated every step)
-constexpr int LIST_B = 32;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
-constexpr int LIST_M = LIST_F + LIST_B;  // uint16 entries per point; lists live in global memory (L2-resident)
-
-// 5 nearest of points ia / ib among entries [E0, E1) of their lists, continuing the running top-5 in ta / tb.
-// The two independent insertion chains are interleaved for ILP.  Entries >= cnt are ignored.
-template <int E0, int E1>
-__device__ __forceinline__ void list_top5_2(const f32x4* __restrict__ X, const uint16_t* La, const uint16_t* Lb,
-                                            int cnt_a, int cnt_b, int ia, int ib, Top5& ta, Top5& tb) {
-    constexpr int NC = (E1 - E0) / 8;
-    const f32x4 xa = X[ia], xb = X[ib];
-    u32x4 wa[NC], wb[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        wa[c] = reinterpret_cast<const u32x4*>(La)[E0 / 8 + c];
-        wb[c] = reinterpret_cast<const u32x4*>(Lb)[E0 / 8 + c];
-    }
-    // One entry of each list per block.  The sched_barrier keeps every compare next to the selects that consume
-    // it: left alone, the scheduler runs the distance chains ahead and parks dozens of lane masks in spilled SGPRs
-    // (v_writelane / v_readlane + s_nop per compare - 2x the instructions).  The next entry's coordinates are
-    // fetched one block ahead to cover the LDS latency.
-    int ja = (int)(wa[0][0] & 0xffffu), jb = (int)(wb[0][0] & 0xffffu);
-    bool va = E0 < cnt_a, vb = E0 < cnt_b;
-    f32x4 na = X[va ? ja : ia], nb = X[vb ? jb : ib];
-#pragma unroll
-    for (int e = E0; e < E1; ++e) {
-        const f32x4 pa_ = na, pb_ = nb;
-        const int cja = ja, cjb = jb;
-        const bool cva = va, cvb = vb;
-        if (e + 1 < E1) {
-            const int r = e + 1 - E0;
-            const unsigned int pka = wa[r >> 3][(r & 7) >> 1], pkb = wb[r >> 3][(r & 7) >> 1];
-            ja = (r & 1) ? (int)(pka >> 16) : (int)(pka & 0xffffu);
-            jb = (r & 1) ? (int)(pkb >> 16) : (int)(pkb & 0xffffu);
-            va = e + 1 < cnt_a;
-            vb = e + 1 < cnt_b;
-            na = X[va ? ja : ia];
-            nb = X[vb ? jb : ib];
-        }
-        const float ax = pa_.x - xa.x, ay = pa_.y - xa.y, az = pa_.z - xa.z;
-        const float bx = pb_.x - xb.x, by = pb_.y - xb.y, bz = pb_.z - xb.z;
-        float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
-        float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
-        da = cva ? da : INFINITY;
-        db = cvb ? db : INFINITY;
-        top5_insert_nb(ta, da, cja);
-        top5_insert_nb(tb, db, cjb);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// ---- fast evaluation: 32-bit keys = (distance bits with the low 10 mantissa bits replaced by the index) --------
-// Positive floats order like their bit patterns, so a running sorted top-6 of keys needs one v_min_u32 and five
-// v_med3_u32 per entry - no compare masks, no index selects (16 instead of ~33 VALU ops per entry).  The 5 smallest
-// keys are EXACTLY the 5 nearest entries whenever key 5 and key 6 differ above the index bits (every other entry
-// is then strictly farther than all five); otherwise (relative distance gap < 2^-13 at the 5/6 boundary, rare) the
-// caller falls back to the exact insertion path.  The order inside the five is irrelevant: the gradient sums are
-// fixed-point (rep_point).  Unused list slots hold index MAXK, the far-away dummy point X[MAXK].
-constexpr unsigned int KEY_IDX_MASK = 1023u;
-struct Keys6 {
-    unsigned int k0, k1, k2, k3, k4, k5;
-};
-__device__ __forceinline__ void keys6_init(Keys6& q) { q.k0 = q.k1 = q.k2 = q.k3 = q.k4 = q.k5 = 0xffffffffu; }
-__device__ __forceinline__ unsigned int umed3(unsigned int a, unsigned int b, unsigned int c) {
-    unsigned int r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ void keys6_insert(Keys6& q, unsigned int x) {
-    q.k5 = umed3(q.k4, q.k5, x);      // new k_i = median(old k_{i-1}, old k_i, x)
-    q.k4 = umed3(q.k3, q.k4, x);
-    q.k3 = umed3(q.k2, q.k3, x);
-    q.k2 = umed3(q.k1, q.k2, x);
-    q.k1 = umed3(q.k0, q.k1, x);
-    q.k0 = min(q.k0, x);
-}
-// wa / wb: the LIST_M / 8 packed index words of the two lists (loaded by the caller in ONE global round trip);
-// chunks [C0, C1) of 8 entries are evaluated.  Per chunk all 16 coordinate reads are issued before the first use:
-// the phase is latency-bound (a lone VALU wave next to an MFMA wave), so LDS round trips are batched, not chained.
-template <int C0, int C1>
-__device__ __forceinline__ void list_keys6_2(const f32x4* __restrict__ X, const u32x4 (&wa)[LIST_M / 8],
-                                             const u32x4 (&wb)[LIST_M / 8], int ia, int ib, Keys6& qa, Keys6& qb) {
-    const f32x4 xa = X[ia], xb = X[ib];
-#pragma unroll
-    for (int c = C0; c < C1; ++c) {
-        unsigned int ja[8], jb[8];
-        f32x4 pa_[8], pb_[8];
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-            const unsigned int pka = wa[c][e8 >> 1], pkb = wb[c][e8 >> 1];
-            ja[e8] = (e8 & 1) ? (pka >> 16) : (pka & 0xffffu);
-            jb[e8] = (e8 & 1) ? (pkb >> 16) : (pkb & 0xffffu);
-        }
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) { pa_[e8] = X[ja[e8]]; pb_[e8] = X[jb[e8]]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-            const float ax = pa_[e8].x - xa.x, ay = pa_[e8].y - xa.y, az = pa_[e8].z - xa.z;
-            const float bx = pb_[e8].x - xb.x, by = pb_[e8].y - xb.y, bz = pb_[e8].z - xb.z;
-            const float da = fmaf(az, az, fmaf(ay, ay, ax * ax));
-            const float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
-            keys6_insert(qa, (__float_as_uint(da) & ~KEY_IDX_MASK) | ja[e8]);
-            keys6_insert(qb, (__float_as_uint(db) & ~KEY_IDX_MASK) | jb[e8]);
-        }
-    }
-}
-__device__ __forceinline__ void load_list_words(const uint16_t* La, const uint16_t* Lb, u32x4 (&wa)[LIST_M / 8],
-                                                u32x4 (&wb)[LIST_M / 8]) {
-#pragma unroll
-    for (int c = 0; c < LIST_M / 8; ++c) {
-        wa[c] = reinterpret_cast<const u32x4*>(La)[c];
-        wb[c] = reinterpret_cast<const u32x4*>(Lb)[c];
-    }
-}
-// upper bound of the squared distance of key k (INF for the init value / NaN patterns)
-__device__ __forceinline__ float key_d_upper(unsigned int k) {
-    return k >= 0x7f800000u ? INFINITY : __uint_as_float(k | KEY_IDX_MASK);
-}
-__device__ __forceinline__ bool keys6_ambiguous(const Keys6& q) { return ((q.k4 ^ q.k5) & ~KEY_IDX_MASK) == 0u; }
-__device__ __forceinline__ void keys6_to_top5(const Keys6& q, Top5& t) {
-    t.i0 = (int)(q.k0 & KEY_IDX_MASK); t.i1 = (int)(q.k1 & KEY_IDX_MASK); t.i2 = (int)(q.k2 & KEY_IDX_MASK);
-    t.i3 = (int)(q.k3 & KEY_IDX_MASK); t.i4 = (int)(q.k4 & KEY_IDX_MASK);
-    t.d0 = t.d1 = t.d2 = t.d3 = 0.f;
-    t.d4 = key_d_upper(q.k4);
-}
-
-// Per-point list state kept by the owning lane.
-struct KnnPt {
-    int cnt_f, cnt_b;   // valid entries of the front / back segment; cnt_b = -1: no valid list (ball too crowded)
-    float rho_f;        // the front holds EVERY point that was within rho_f at build time (0: front not complete)
-    float rho_b;        // front + back hold every point that was within rho_b at build time
-    float al_f, al_b;   // alpha^2 of the two radii: rho^2 = al * (upper bound of the squared 5-NN distance)
-    f32x4 x0;           // position at build time
-    float dbase;        // Dmax at this point's build time (0 for whole-cloud rebuilds, which start a new epoch)
-    float r5p;          // last step's 5-NN distance (upper bound)
-    bool frag;          // certificate too short-lived to be worth a whole-cloud rebuild: refreshed individually
-    bool pend;          // individual refresh requested for the next step
-};
-
-// One target of the wave-cooperative ("transposed") list build: the lanes hold the K candidate points in registers
-// (16 each); one distance per candidate, hits are compacted with ballot / mbcnt into the target's list - no divergent
-// branches, exact counts.  tf / tb: squared front / back radii (wave-uniform).  Unused slots get the dummy index.
-__device__ __forceinline__ void knn_build_one(const float (&cx)[16], const float (&cy)[16], const float (&cz)[16],
-                                              const f32x4 xi, int i, int lane, float tf, float tb,
-                                              uint16_t* __restrict__ lst, int& nf_out, int& nb_out) {
-    int nf = 0, nb = 0;                                                            // wave-uniform running counts
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int j = lane + 64 * k;
-        const float ex = cx[k] - xi.x, ey = cy[k] - xi.y, ez = cz[k] - xi.z;
-        const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-        const bool in_b = d < tb && j != i;
-        const bool in_f = d < tf && in_b;
-        const unsigned long long mf = __ballot(in_f);
-        const int pos_f = nf + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
-        const bool to_f = in_f && pos_f < LIST_F;
-        if (to_f) lst[pos_f] = (uint16_t)j;
-        nf += __popcll(mf);
-        const bool to_b = in_b && !to_f;                  // ring members + front hits that did not fit
-        const unsigned long long mb = __ballot(to_b);
-        const int pos_b = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
-        if (to_b && pos_b < LIST_B) lst[LIST_F + pos_b] = (uint16_t)j;
-        nb += __popcll(mb);
-    }
-    // unused slots point at the dummy X[MAXK] (the key evaluation does not look at counts)
-    if (lane < LIST_M && lane >= (lane < LIST_F ? nf : LIST_F + nb)) lst[lane] = (uint16_t)MAXK;
-    nf_out = nf;
-    nb_out = nb;
-}
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-// (Re)build the lists of the flagged points of this wave (need_a / need_b per lane; d4a / d4b: upper bounds of their
-// squared 5-NN distances at the current positions).  Targets are taken one at a time off the ballot mask, so the
-// cost is ~1 us for loading the candidates plus ~0.5 us per target - whole-cloud rebuilds (all flagged) and the
-// individual refreshes of short-lived ("fragile") certificates share this code.  A ball that overflows its list is
-// shrunk in proportion to the overshoot (hit count ~ r^2 on a surface) and rebuilt on the spot.
-__device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, int wave, int lane,
-                                            uint16_t* __restrict__ lists, bool need_a, bool need_b, float d4a,
-                                            float d4b, KnnPt& ka, KnnPt& kb, float dbase, float mv,
-                                            unsigned int& n_targets, unsigned int& n_repass) {
-    float cx[16], cy[16], cz[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int j = lane + 64 * k;
-        const f32x4 p = X[min(j, K - 1)];
-        const bool v = j < K;
-        cx[k] = v ? p.x : 1e18f; cy[k] = v ? p.y : 1e18f; cz[k] = v ? p.z : 1e18f;
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        KnnPt& kp = half ? kb : ka;
-        const float d4 = half ? d4b : d4a;
-        const float my_tf = d4 * kp.al_f, my_tb = d4 * kp.al_b;
-        unsigned long long mask = __ballot(half ? need_b : need_a);
-#pragma unroll 1
-        while (mask != 0ull) {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const int i = (half ? OPT_THREADS : 0) + wave * 64 + l;
-            float tf = readlane_f(my_tf, l), tb = readlane_f(my_tb, l);
-            const f32x4 xi = X[i];                                                   // wave-uniform address
-            uint16_t* lst = lists + (size_t)i * LIST_M;
-            int nf, nb;
-            ++n_targets;
-#pragma unroll 1
-            for (int rep = 0;; ++rep) {
-                knn_build_one(cx, cy, cz, xi, i, lane, tf, tb, lst, nf, nb);
-                if ((nf <= LIST_F && nb <= LIST_B) || rep == 3) break;
-                ++n_repass;
-                const float n_in = (float)(min(nf, LIST_F) + nb);                   // points inside the back radius
-                float nf_new = (float)nf;
-                if (nf > LIST_F) { tf *= (0.7f * LIST_F) / (float)nf; nf_new = 0.7f * LIST_F; }
-                if (n_in - nf_new > 0.85f * LIST_B) tb *= (nf_new + 0.75f * LIST_B) / n_in;
-                tb = fmaxf(tb, tf);
-            }
-            if (lane == l) {
-                kp.cnt_f = min(nf, LIST_F);
-                kp.rho_f = nf <= LIST_F ? sqrtf(tf) : 0.f;          // front complete only if everything fitted
-                kp.cnt_b = nb <= LIST_B ? nb : -1;
-                kp.rho_b = sqrtf(tb);
-                // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly when sparse
-                if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb / d4; }
-                if (nf < LIST_F / 2) kp.al_f *= 1.15f;
-                if (nf + nb < LIST_M / 2) kp.al_b *= 1.15f;
-                kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
-                kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
-                kp.al_f = fminf(kp.al_f, kp.al_b);
-                kp.x0 = xi;
-                kp.dbase = dbase;
-                // expected lifetime of the certificate ~ (rho - r5 - 6 mv) / (~2 mv per step)
-#ifndef IFD_FRAG_MULT
-#define IFD_FRAG_MULT 16.f
-#endif
-                kp.frag = kp.rho_b - sqrtf(d4) < IFD_FRAG_MULT * mv;
-            }
-        }
-    }
-}
-
-struct RepConst {
-    float radius, h, eps;
-};
-
-// Loss and gradient terms of one centre point (repulsion_loss.py:43-53).  The centre part is
-// returned in gc (un-scaled), neighbour parts go to the fixed-point LDS accumulator.
-__device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long* __restrict__ F, int i,
-                                          const Top5& t, const RepConst rc, float& loss, long long (&gc)[3],
-                                          bool want_grad) {
-    const f32x4 xi = X[i];
-    const int idx[5] = {t.i0, t.i1, t.i2, t.i3, t.i4};
-    loss = 0.f;
-    gc[0] = gc[1] = gc[2] = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int j = idx[k];
-        const f32x4 xj = X[j];
-        const float ex = xj.x - xi.x, ey = xj.y - xi.y, ez = xj.z - xi.z;
-        const float d2raw = ex * ex + ey * ey + ez * ez;
-        const float d2 = fmaxf(d2raw, rc.eps);
-        const float d = sqrtf(d2);
-        const float q = d / rc.h;
-        const float w = expf(-(q * q));
-        loss += (rc.radius - d) * w;
-        if (want_grad) {
-            // dL/dd = -w - (r-d) w 2 d / h^2 ; chain through sqrt and the clamp (zero below eps)
-            const float dd = -w - (rc.radius - d) * w * (2.f * q / rc.h);
-            const float coef = d2raw > rc.eps ? dd / d : 0.f;
-            const float gx = coef * ex, gy = coef * ey, gz = coef * ez;
-            // fixed point on both ends: the sums do not depend on the order of the neighbours or of the atomics,
-            // and the centre receives exactly minus what its neighbours receive
-            const long long fx = __float2ll_rn(gx * FIX_SCALE), fy = __float2ll_rn(gy * FIX_SCALE),
-                            fz = __float2ll_rn(gz * FIX_SCALE);
-            gc[0] -= fx; gc[1] -= fy; gc[2] -= fz;
-            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 0), (unsigned long long)fx);
-            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 1), (unsigned long long)fy);
-            atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * j + 2), (unsigned long long)fz);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// block helpers
-// ---------------------------------------------------------------------------------------------
-constexpr int OWN_WAVES = OPT_THREADS / 64;   // waves whose threads own points (kNN / Adam duty): threads [0, 512)
-constexpr int MAX_WAVES = 16;
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-// deterministic block reductions; `scratch` holds >= NWAVES floats
-__device__ __forceinline__ float block_sum(float v, float* scratch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    float s = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += scratch[w];
-    return s;
-}
-__device__ __forceinline__ float block_max(float v, float* scratch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_max(v);
-    __syncthreads();
-    if (lane == 0) scratch[wave] = v;
-    __syncthreads();
-    float s = scratch[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s = fmaxf(s, scratch[w]);
-    return s;
-}
-
 __device__ __forceinline__ void load_dec_image(float* __restrict__ W, const float* __restrict__ img) {
     for (int i = threadIdx.x * 4; i < DEC_FLOATS; i += blockDim.x * 4)
         *reinterpret_cast<f32x4*>(W + i) = *reinterpret_cast<const f32x4*>(img + i);
-}
-
-// normalize_batch_pc (opt_defense.py:76-83) on the cloud held in X; two points per thread.
-__device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, float* scratch) {
-    const bool owner = threadIdx.x < OPT_THREADS;
-    const int pa = owner ? (int)threadIdx.x : MAXK, pb = owner ? (int)threadIdx.x + OPT_THREADS : MAXK;
-    f32x4 a = pa < K ? X[pa] : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 b = pb < K ? X[pb] : f32x4{0.f, 0.f, 0.f, 0.f};
-    const float cx = block_sum(a.x + b.x, scratch) / (float)K;
-    const float cy = block_sum(a.y + b.y, scratch) / (float)K;
-    const float cz = block_sum(a.z + b.z, scratch) / (float)K;
-    a.x -= cx; a.y -= cy; a.z -= cz;
-    b.x -= cx; b.y -= cy; b.z -= cz;
-    const float da = pa < K ? sqrtf(a.x * a.x + a.y * a.y + a.z * a.z) : 0.f;
-    const float db = pb < K ? sqrtf(b.x * b.x + b.y * b.y + b.z * b.z) : 0.f;
-    const float md = block_max(fmaxf(da, db), scratch);
-    if (pa < K) X[pa] = f32x4{a.x / md, a.y / md, a.z / md, 0.f};
-    if (pb < K) X[pb] = f32x4{b.x / md, b.y / md, b.z / md, 0.f};
-    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1377,7 +976,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
-    float mm[6], vv[6];
+    AdamState ast;
+    float (&mm)[6] = ast.mm;
+    float (&vv)[6] = ast.vv;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int pt = q ? pb : pa;
@@ -1403,7 +1004,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float inv_lb = 1.0f / (float)loss_batch;
     const float rep_scale = A.rep_weight / ((float)loss_batch * (float)K * 5.f);
     const bool use_rep = A.rep_weight > 0.f;
-    double b1t = pow(0.9, (double)A.t0), b2t = pow(0.999, (double)A.t0);
+    ast.b1t = pow(0.9, (double)A.t0);
+    ast.b2t = pow(0.999, (double)A.t0);
     float rep_loss_a = 0.f, rep_loss_b = 0.f;
     // certified neighbour lists of the two owned points
     uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;   // global (L2-resident)
@@ -1415,15 +1017,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     float* movebuf = scratch + 64;                                   // [2][MAX_WAVES] per-wave max single-step move
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
     int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
-    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0, n_tier2 = 0, n_exact = 0, n_refresh = 0, n_targets = 0;
-#ifdef IFD_PROF      // cycle accounting of cloud 0 (diagnostic builds only; overwrites the counters)
-    unsigned long long pc_build = 0, pc_eval = 0, pc_rep = 0, pc_tiles = 0, pc_wait = 0, pc_adam = 0, pc_t = 0;
-#define PROF_T0() pc_t = __builtin_readcyclecounter()
-#define PROF_ACC(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); v += n_ - pc_t; pc_t = n_; } while (0)
-#else
-#define PROF_T0()
-#define PROF_ACC(v)
-#endif
+    KnnCounters cn;
+    const KnnShared ksh = {dmaxbuf, movebuf, rebuild_flag};
     if (tid < 2) rebuild_flag[tid] = 0;
     if (tid == 0) *tile_ctr = 0;
     if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
@@ -1439,147 +1034,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #pragma unroll 1
         for (int phase = 0; phase < 2; ++phase) {
             if (phase == 1 && wave < OWN_WAVES && use_rep) {
-                Top5 ta, tb;
-                top5_init(ta);
-                top5_init(tb);
-                const int ia = min(pa, K - 1), ib = min(pb, K - 1);
-                if (A.knn_scan_every_step) {
-                    knn_scan2(X, K, pa, pb, ta, tb);
-                } else {
-                    const bool force = step == 0 || rebuild_flag[step & 1] != 0;      // block-uniform
-                    float dmax = 0.f, mv = 0.f;
-#pragma unroll
-                    for (int w = 0; w < OWN_WAVES; ++w) {
-                        dmax = fmaxf(dmax, dmaxbuf[(step & 1) * MAX_WAVES + w]);
-                        mv = fmaxf(mv, movebuf[(step & 1) * MAX_WAVES + w]);
-                    }
-                    // the certificate must survive one more step: r5 grows <= 2 mv, both displacements <= mv
-                    const float soft_slack = 6.f * mv;
-                    PROF_T0();
-                    const bool need_a = pa < K && (force || ka.pend), need_b = pb < K && (force || kb.pend);
-                    if (__any(need_a || need_b)) {
-                        float d4a, d4b;        // upper bounds of the squared 5-NN distances at the current positions
-                        if (force) {
-                            // ---- synchronous whole-cloud rebuild (every owner wave, this step): new epoch ---------
-                            ++n_rebuild;
-                            // any 5 members of the current lists (a truncated ring still holds valid points), else scan
-                            bool have = step != 0;
-                            if (have) {
-                                Keys6 qa, qb;
-                                keys6_init(qa);
-                                keys6_init(qb);
-                                u32x4 wa[LIST_M / 8], wb[LIST_M / 8];
-                                load_list_words(La, Lb, wa, wb);
-                                list_keys6_2<0, LIST_M / 8>(X, wa, wb, ia, ib, qa, qb);
-                                ta.d4 = key_d_upper(qa.k4);
-                                tb.d4 = key_d_upper(qb.k4);
-                                have = ta.d4 < 1e30f && tb.d4 < 1e30f;       // the dummy point is ~3e36 away
-                            }
-                            if (!__all(have)) {
-                                ++n_pass;
-                                knn_scan2(X, K, pa, pb, ta, tb);
-                            }
-                            d4a = ta.d4;
-                            d4b = tb.d4;
-                            dmax = 0.f;
-                        } else {
-                            // ---- individual refresh of fragile certificates: r5 grows by at most 2 mv per step ----
-                            ++n_refresh;
-                            const float ra = ka.r5p + 2.f * mv, rb = kb.r5p + 2.f * mv;
-                            d4a = ra * ra;
-                            d4b = rb * rb;
-                        }
-                        knn_refresh(X, K, wave, lane, cloud_lists, need_a, need_b, d4a, d4b, ka, kb, dmax, mv,
-                                    n_targets, n_pass);
-                    }
-                    ka.pend = kb.pend = false;
-                    PROF_ACC(pc_build);
-                    // ---- tier 1: the front ball -----------------------------------------------------------------
-                    const f32x4 xa = X[ia], xb = X[ib];
-                    const float da0 = sqrtf((xa.x - ka.x0.x) * (xa.x - ka.x0.x) + (xa.y - ka.x0.y) * (xa.y - ka.x0.y) +
-                                            (xa.z - ka.x0.z) * (xa.z - ka.x0.z));
-                    const float db0 = sqrtf((xb.x - kb.x0.x) * (xb.x - kb.x0.x) + (xb.y - kb.x0.y) * (xb.y - kb.x0.y) +
-                                            (xb.z - kb.x0.z) * (xb.z - kb.x0.z));
-                    // displacement budget already spent: own move since the build + everybody else's (since the epoch
-                    // reference: now, and at this point's build time).  A list built THIS step is exact as it stands.
-                    const float spent_a = da0 + dmax + ka.dbase, spent_b = db0 + dmax + kb.dbase;
-                    const float hs_a = need_a ? 0.f : spent_a, hs_b = need_b ? 0.f : spent_b;
-                    bool exact = last;       // the reported loss sums the five terms in ascending-distance order
-                    bool soft_a = true, soft_b = true;
-                    if (!exact) {
-                        // ---- fast path: key networks (see list_keys6_2) ------------------------------------------
-                        Keys6 qa, qb;
-                        keys6_init(qa);
-                        keys6_init(qb);
-                        u32x4 wa[LIST_M / 8], wb[LIST_M / 8];
-                        load_list_words(La, Lb, wa, wb);       // front and ring together: one L2 round trip
-                        list_keys6_2<0, LIST_F / 8>(X, wa, wb, ia, ib, qa, qb);
-                        float r5a = sqrtf(key_d_upper(qa.k4)), r5b = sqrtf(key_d_upper(qb.k4));
-                        // every point outside a ball of build radius rho is now farther than rho - (spent budget)
-                        const bool ok1 = (pa >= K || r5a < (ka.rho_f - hs_a) * 0.99999f - 1e-7f) &&
-                                         (pb >= K || r5b < (kb.rho_f - hs_b) * 0.99999f - 1e-7f);
-                        bool scanned = false;
-                        if (!__all(ok1)) {
-                            ++n_tier2;
-                            list_keys6_2<LIST_F / 8, LIST_M / 8>(X, wa, wb, ia, ib, qa, qb);
-                            r5a = sqrtf(key_d_upper(qa.k4));
-                            r5b = sqrtf(key_d_upper(qb.k4));
-                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f)) &&
-                                              (pb >= K || (kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f));
-                            if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
-                                ++n_brute;
-                                knn_scan2(X, K, pa, pb, ta, tb);
-                                scanned = true;
-                            }
-                            // will it still hold next step?  (crowded balls, cnt_b < 0, are served by the scan anyway)
-                            soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
-                            soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
-                        }
-                        if (!scanned) {
-                            const bool amb = (pa < K && keys6_ambiguous(qa)) || (pb < K && keys6_ambiguous(qb));
-                            if (__any(amb)) {
-                                exact = true;
-                            } else {
-                                keys6_to_top5(qa, ta);
-                                keys6_to_top5(qb, tb);
-                            }
-                        }
-                    }
-                    if (exact) {
-                        // ---- exact path: sorted insertion with indices (last step, near-ties) --------------------
-                        ++n_exact;
-                        soft_a = soft_b = true;
-                        top5_init(ta);
-                        top5_init(tb);
-                        list_top5_2<0, LIST_F>(X, La, Lb, ka.cnt_f, kb.cnt_f, ia, ib, ta, tb);
-                        const bool ok1 = (pa >= K || sqrtf(ta.d4) < (ka.rho_f - hs_a) * 0.99999f - 1e-7f) &&
-                                         (pb >= K || sqrtf(tb.d4) < (kb.rho_f - hs_b) * 0.99999f - 1e-7f);
-                        if (!__all(ok1)) {
-                            list_top5_2<LIST_F, LIST_M>(X, La, Lb, LIST_F + ka.cnt_b, LIST_F + kb.cnt_b, ia, ib, ta, tb);
-                            const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
-                            const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f)) &&
-                                              (pb >= K || (kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f));
-                            if (!__all(hard)) {
-                                ++n_brute;
-                                knn_scan2(X, K, pa, pb, ta, tb);
-                            }
-                            soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
-                            soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
-                        }
-                    }
-                    ka.r5p = sqrtf(ta.d4);
-                    kb.r5p = sqrtf(tb.d4);
-                    // a certificate about to expire: fragile ones are refreshed individually next step, the others
-                    // mean the epoch is old -> whole-cloud rebuild next step
-                    ka.pend = !soft_a && ka.frag;
-                    kb.pend = !soft_b && kb.frag;
-                    const bool soft_ok = (soft_a || ka.frag) && (soft_b || kb.frag);
-                    if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
-                    PROF_ACC(pc_eval);
-                }
-                if (pa < K) rep_point(X, F, pa, ta, rc, rep_loss_a, gca, true);
-                if (pb < K) rep_point(X, F, pb, tb, rc, rep_loss_b, gcb, true);
-                PROF_ACC(pc_rep);
+                knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb,
+                          ksh, rc, rep_loss_a, rep_loss_b, gca, gcb, cn);
             }
             PROF_T0();
             // decoder tiles: phase 0 = up to `quota` tiles before the kNN, phase 1 = until the step's tiles run out
@@ -1627,75 +1083,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
         }
-        // ---- Adam (torch/optim/adam.py _single_tensor_adam: lerp form, eps added after the bias-
-        //      corrected sqrt) ---------------------------------------------------------------------
-        b1t *= 0.9;
-        b2t *= 0.999;
-        const float step_size = (float)((double)A.lr / (1.0 - b1t));
-        const float bc2 = (float)sqrt(1.0 - b2t);
-        float dmax2 = 0.f, mv2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int pt = q ? pb : pa;
-            if (pt < K) {
-                const f32x4 go = G[pt];
-                const f32x4 x = X[pt];
-                const float gocc[3] = {go.x, go.y, go.z};
-                float xs[3] = {x.x, x.y, x.z};
-                float msq = 0.f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float gn = __ll2float_rn(F[3 * pt + a] + (q ? gcb[a] : gca[a])) * FIX_INV;
-                    F[3 * pt + a] = 0;
-                    const float gr = gn * rep_scale;
-                    const float g = gocc[a] + gr;
-                    float& mr = mm[3 * q + a];
-                    float& vr = vv[3 * q + a];
-                    mr = mr + (g - mr) * (1.f - 0.9f);
-                    vr = vr * 0.999f + (1.f - 0.999f) * g * g;
-                    const float denom = sqrtf(vr) / bc2 + 1e-8f;
-                    const float upd = step_size * (mr / denom);
-                    xs[a] = xs[a] - upd;
-                    msq = fmaf(upd, upd, msq);
-                }
-                const f32x4 x0 = q ? kb.x0 : ka.x0;
-                const float dsq = (xs[0] - x0.x) * (xs[0] - x0.x) + (xs[1] - x0.y) * (xs[1] - x0.y) +
-                                  (xs[2] - x0.z) * (xs[2] - x0.z);
-                dmax2 = fmaxf(dmax2, sqrtf(dsq) + (q ? kb.dbase : ka.dbase));
-                mv2 = fmaxf(mv2, msq);
-                X[pt] = f32x4{xs[0], xs[1], xs[2], 0.f};
-            }
-        }
-        dmax2 = wave_max(dmax2);
-        mv2 = wave_max(mv2);
-        if (lane == 0) {
-            dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = dmax2 * 1.00001f + 1e-7f;
-            movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
-        }
+        adam_phase(X, G, F, K, pa, pb, wave, lane, step, A.lr, rep_scale, gca, gcb, ast, ka, kb, ksh);
         if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
         __syncthreads();
         PROF_ACC(pc_adam);
     }
 
     if (counters != nullptr && lane == 0) {
-        atomicAdd(counters + 0, (unsigned long long)n_rebuild);   // wave-level list rebuilds
-        atomicAdd(counters + 1, (unsigned long long)n_brute);     // wave-level certificate failures (exact scans)
-        atomicAdd(counters + 2, (unsigned long long)n_pass);      // extra rebuild work: exact scans for radii + overflow re-passes
-        atomicAdd(counters + 4, (unsigned long long)n_tier2);     // wave-steps that had to evaluate the back ring
-        atomicAdd(counters + 5, (unsigned long long)n_exact);     // wave-steps on the exact insertion path (last step, near-ties)
-        atomicAdd(counters + 6, (unsigned long long)n_refresh);   // wave-steps with individual list refreshes
-        atomicAdd(counters + 7, (unsigned long long)n_targets);   // lists built (whole-cloud rebuilds + individual refreshes)
+        atomicAdd(counters + 0, (unsigned long long)cn.n_rebuild);   // wave-level list rebuilds
+        atomicAdd(counters + 1, (unsigned long long)cn.n_brute);     // wave-level certificate failures (exact scans)
+        atomicAdd(counters + 2, (unsigned long long)cn.n_pass);      // extra rebuild work: exact scans for radii + overflow re-passes
+        atomicAdd(counters + 4, (unsigned long long)cn.n_tier2);     // wave-steps that had to evaluate the back ring
+        atomicAdd(counters + 5, (unsigned long long)cn.n_exact);     // wave-steps on the exact insertion path (last step, near-ties)
+        atomicAdd(counters + 6, (unsigned long long)cn.n_refresh);   // wave-steps with individual list refreshes
+        atomicAdd(counters + 7, (unsigned long long)cn.n_targets);   // lists built (whole-cloud rebuilds + individual refreshes)
         if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
 #ifdef IFD_PROF
         if (tid == 0) {
             const unsigned long long cyc = __builtin_readcyclecounter() - t_begin;
             atomicMax(counters + 14, cyc);
-            atomicMax(counters + 13, (unsigned long long)n_rebuild << 32);
+            atomicMax(counters + 13, (unsigned long long)cn.n_rebuild << 32);
             atomicAdd(counters + 15, cyc);
         }
         if (cloud == 0) {
-            atomicAdd(counters + 8, pc_build); atomicAdd(counters + 9, pc_eval); atomicAdd(counters + 10, pc_rep);
-            atomicAdd(counters + 11, pc_tiles); atomicAdd(counters + 12, pc_wait); atomicAdd(counters + 13, pc_adam);
+            atomicAdd(counters + 8, cn.pc_build); atomicAdd(counters + 9, cn.pc_eval); atomicAdd(counters + 10, cn.pc_rep);
+            atomicAdd(counters + 11, cn.pc_tiles); atomicAdd(counters + 12, cn.pc_wait); atomicAdd(counters + 13, cn.pc_adam);
         }
 #endif
     }
