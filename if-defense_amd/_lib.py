@@ -57,6 +57,14 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ifd_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ifd_normalize_unit_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    # ONet-Opt variant
+    "ifd_onet_weight_count": (C.c_size_t, []),
+    "ifd_onet_create": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int]),
+    "ifd_onet_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ifd_onet_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "ifd_onet_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

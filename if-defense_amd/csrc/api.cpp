@@ -90,6 +90,13 @@ struct ifd_ctx {
     unsigned long long* d_counters = nullptr;   // IFD_N_COUNTERS diagnostic counters of the last ifd_optimize
     void* ws = nullptr;            // context-owned scratch (kNN lists, encoder activations), grown on demand
     size_t ws_bytes = 0;
+    // ONet-Opt variant (ifd_onet_create): padded copy of the canonical weights, fragment-ordered decoder layer images
+    // (10 forward + 10 transposed), the small decoder parameters, tensor offsets into d_w
+    int model = IFD_MODEL_CONVONET;
+    float* d_onet_img = nullptr;
+    float* d_onet_small = nullptr;
+    OnetEncOffsets oe{};
+    OnetDecOffsets od{};
     std::string err;
 };
 
@@ -193,6 +200,69 @@ UNetPack pack_unet(const float* w) {
     return P;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ONet-Opt: canonical weight order (include/ifd.h) = the reference checkpoint's state_dict order without the
+// num_batches_tracked scalars: decoder.* then encoder.*
+// ---------------------------------------------------------------------------------------------
+struct OnetTensor { size_t host_off, dev_off, n; };
+struct OnetMap {
+    OnetTensor fc_p_w, fc_p_b, cbn[11][6] /* gamma.w, gamma.b, beta.w, beta.b, mean, var */, fc0_w[5], fc0_b[5], fc1_w[5],
+        fc1_b[5], out_w, out_b;
+    OnetTensor pos_w, pos_b, e_fc0_w[5], e_fc0_b[5], e_fc1_w[5], e_fc1_b[5], e_sc_w[5], fcc_w, fcc_b;
+    size_t host_total, dev_total;
+};
+OnetMap make_onet_map() {
+    OnetMap m{};
+    size_t ho = 0, dv = 0;
+    auto take = [&](size_t n) {
+        OnetTensor t{ho, dv, n};
+        ho += n;
+        dv += (n + 3) & ~(size_t)3;          // device copy: every tensor starts on a 16-byte boundary
+        return t;
+    };
+    auto cbn = [&](int i) {
+        m.cbn[i][0] = take((size_t)ONET_H * ONET_C); m.cbn[i][1] = take(ONET_H);
+        m.cbn[i][2] = take((size_t)ONET_H * ONET_C); m.cbn[i][3] = take(ONET_H);
+        m.cbn[i][4] = take(ONET_H); m.cbn[i][5] = take(ONET_H);
+    };
+    m.fc_p_w = take(ONET_H * 3); m.fc_p_b = take(ONET_H);
+    for (int i = 0; i < 5; ++i) {
+        cbn(2 * i); cbn(2 * i + 1);
+        m.fc0_w[i] = take((size_t)ONET_H * ONET_H); m.fc0_b[i] = take(ONET_H);
+        m.fc1_w[i] = take((size_t)ONET_H * ONET_H); m.fc1_b[i] = take(ONET_H);
+    }
+    cbn(10);
+    m.out_w = take(ONET_H); m.out_b = take(1);
+    const size_t H = ONET_ENC_H;
+    m.pos_w = take(2 * H * 3); m.pos_b = take(2 * H);
+    for (int i = 0; i < 5; ++i) {
+        m.e_fc0_w[i] = take(H * 2 * H); m.e_fc0_b[i] = take(H);
+        m.e_fc1_w[i] = take(H * H); m.e_fc1_b[i] = take(H);
+        m.e_sc_w[i] = take(H * 2 * H);
+    }
+    m.fcc_w = take((size_t)ONET_C * H); m.fcc_b = take(ONET_C);
+    m.host_total = ho; m.dev_total = dv;
+    return m;
+}
+const OnetMap& omap() {
+    static const OnetMap m = make_onet_map();
+    return m;
+}
+
+// Fragment-ordered image of one 256x256 layer for the 16x16x4 MFMA A operand (onet.hip): [tile t][4 k-steps s4]
+// [lane][4]; lane (m = l & 15, q = l >> 4) of k-step s = 4 s4 + j multiplies input channel 16 (s >> 2) + 4 q + (s & 3).
+void onet_fragment_image(const float* W, bool transposed, float* img) {
+    for (int t = 0; t < 16; ++t)
+        for (int s4 = 0; s4 < 16; ++s4)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 16 * t + (lane & 15), q = lane >> 4, s = 4 * s4 + j;
+                    const int k = 16 * (s >> 2) + 4 * q + (s & 3);
+                    img[(((size_t)t * 16 + s4) * 64 + lane) * 4 + j] = transposed ? W[(size_t)k * ONET_H + m] : W[(size_t)m * ONET_H + k];
+                }
+}
+
 }  // namespace
 
 extern "C" {
@@ -281,6 +351,8 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->d_w) (void)hipFree(ctx->d_w);
     if (ctx->d_unet) (void)hipFree(ctx->d_unet);
     if (ctx->ws_enc) (void)hipFree(ctx->ws_enc);
+    if (ctx->d_onet_img) (void)hipFree(ctx->d_onet_img);
+    if (ctx->d_onet_small) (void)hipFree(ctx->d_onet_small);
     delete ctx;
 }
 
@@ -312,6 +384,7 @@ int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, 
 int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* planes_pre,
                       float* c_points, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_encode_points: not a ConvONet context");
     if (!sel || !planes_pre || B < 1 || Tmax < 1 || Tmax > 1024)
         return fail(ctx, IFD_ERR_ARG, "ifd_encode_points: bad argument (1 <= Tmax <= 1024)");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -323,6 +396,7 @@ int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
 
 int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_unet: not a ConvONet context");
     if (!planes_pre || !planes || B < 1) return fail(ctx, IFD_ERR_ARG, "ifd_unet: bad argument");
     hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, unet_workspace_floats(3 * B) * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_unet workspace", e);
@@ -333,6 +407,7 @@ int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* 
 int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* planes,
                       void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_encode_planes: not a ConvONet context");
     if (!sel || !planes || B < 1 || Tmax < 1 || Tmax > 1024)
         return fail(ctx, IFD_ERR_ARG, "ifd_encode_planes: bad argument (1 <= Tmax <= 1024)");
     // scratch = [pre-U-Net planes | U-Net activations]
@@ -350,6 +425,7 @@ int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
 int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,
                void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_decode: not a ConvONet context (use ifd_onet_decode)");
     if (!planes || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_decode: bad argument");
     hipError_t e = launch_decode(ctx->d_dec_img, planes, p, B, K, logits, dlogit_dp, ctx->dc,
                                  static_cast<hipStream_t>(stream));
@@ -368,6 +444,7 @@ int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, const ifd_opt_params* prm,
                  const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: not a ConvONet context (use ifd_onet_optimize)");
     if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 1024)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: pass both m and v or neither");
@@ -404,6 +481,152 @@ int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream
     if (!p || B < 1 || K < 1 || K > MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument");
     hipError_t e = launch_normalize(p, B, K, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_normalize launch", e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONet-Opt variant
+// ---------------------------------------------------------------------------------------------
+size_t ifd_onet_weight_count(void) { return omap().host_total; }
+
+ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device) {
+    g_create_error.clear();
+    const OnetMap& m = omap();
+    if (!weights_host) { g_create_error = "ifd_onet_create: NULL argument"; return nullptr; }
+    if (n_weights != m.host_total) {
+        g_create_error = "ifd_onet_create: expected " + std::to_string(m.host_total) + " weights, got " + std::to_string(n_weights);
+        return nullptr;
+    }
+    ifd_ctx* ctx = new (std::nothrow) ifd_ctx();
+    if (!ctx) { g_create_error = "ifd_onet_create: out of host memory"; return nullptr; }
+    ctx->device = device;
+    ctx->model = IFD_MODEL_ONET;
+    ctx->w.assign(weights_host, weights_host + n_weights);
+    const float* w = ctx->w.data();
+    // padded device copy
+    std::vector<float> dev(m.dev_total, 0.f);
+    auto put = [&](const OnetTensor& t) { std::memcpy(dev.data() + t.dev_off, w + t.host_off, t.n * sizeof(float)); return (int)t.dev_off; };
+    put(m.fc_p_w); put(m.fc_p_b);
+    OnetDecOffsets& od = ctx->od;
+    for (int i = 0; i < 11; ++i) {
+        od.cbn_gamma_w[i] = put(m.cbn[i][0]); od.cbn_gamma_b[i] = put(m.cbn[i][1]);
+        od.cbn_beta_w[i] = put(m.cbn[i][2]); od.cbn_beta_b[i] = put(m.cbn[i][3]);
+        od.cbn_mean[i] = put(m.cbn[i][4]); od.cbn_var[i] = put(m.cbn[i][5]);
+    }
+    for (int i = 0; i < 5; ++i) { put(m.fc0_w[i]); od.fc0_b[i] = put(m.fc0_b[i]); put(m.fc1_w[i]); put(m.fc1_b[i]); }
+    put(m.out_w); put(m.out_b);
+    OnetEncOffsets& oe = ctx->oe;
+    oe.pos_w = put(m.pos_w); oe.pos_b = put(m.pos_b);
+    for (int i = 0; i < 5; ++i) {
+        oe.fc0_w[i] = put(m.e_fc0_w[i]); oe.fc0_b[i] = put(m.e_fc0_b[i]);
+        oe.fc1_w[i] = put(m.e_fc1_w[i]); oe.fc1_b[i] = put(m.e_fc1_b[i]);
+        oe.sc_w[i] = put(m.e_sc_w[i]);
+    }
+    oe.fcc_w = put(m.fcc_w); oe.fcc_b = put(m.fcc_b);
+    // decoder layer images: forward fc_0 / fc_1 of blocks 0..4, then the transposes in backward order
+    const size_t L = (size_t)ONET_H * ONET_H;
+    std::vector<float> img(20 * L);
+    for (int i = 0; i < 5; ++i) {
+        onet_fragment_image(w + m.fc0_w[i].host_off, false, img.data() + (size_t)(2 * i) * L);
+        onet_fragment_image(w + m.fc1_w[i].host_off, false, img.data() + (size_t)(2 * i + 1) * L);
+        onet_fragment_image(w + m.fc1_w[i].host_off, true, img.data() + (size_t)(10 + 2 * (4 - i)) * L);
+        onet_fragment_image(w + m.fc0_w[i].host_off, true, img.data() + (size_t)(11 + 2 * (4 - i)) * L);
+    }
+    // small parameters, in the LDS order of onet.hip: fc_p [256][4] | fc_1 biases [5][256] | fc_out w [256] | b
+    std::vector<float> small((size_t)onet_small_floats(), 0.f);
+    for (int c = 0; c < ONET_H; ++c) {
+        for (int a = 0; a < 3; ++a) small[c * 4 + a] = w[m.fc_p_w.host_off + c * 3 + a];
+        small[c * 4 + 3] = w[m.fc_p_b.host_off + c];
+    }
+    for (int i = 0; i < 5; ++i)
+        for (int c = 0; c < ONET_H; ++c) small[ONET_H * 4 + i * ONET_H + c] = w[m.fc1_b[i].host_off + c];
+    for (int c = 0; c < ONET_H; ++c) small[ONET_H * 4 + 5 * ONET_H + c] = w[m.out_w.host_off + c];
+    small[ONET_H * 4 + 5 * ONET_H + ONET_H] = w[m.out_b.host_off];
+
+    hipError_t e = hipSetDevice(device);
+    auto upload = [&](float** dst, const std::vector<float>& src) {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice);
+    };
+    upload(&ctx->d_w, dev);
+    upload(&ctx->d_onet_img, img);
+    upload(&ctx->d_onet_small, small);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), IFD_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = configure_prep_kernels();
+    if (e == hipSuccess) e = configure_optimize_kernels();
+    if (e == hipSuccess) e = configure_onet_kernels();
+    if (e != hipSuccess) {
+        g_create_error = std::string("ifd_onet_create: ") + hipGetErrorString(e);
+        ifd_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+int ifd_onet_encode(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* c, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_encode: not an ONet context");
+    if (!sel || !c || B < 1 || Tmax < 1 || Tmax > 1024) return fail(ctx, IFD_ERR_ARG, "ifd_onet_encode: bad argument (1 <= Tmax <= 1024)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int chunk = 256;                                     // clouds per pass: ~0.8 GB of activations at T = 300
+    hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, onet_encode_ws_floats(B < chunk ? B : chunk, Tmax) * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_encode workspace", e);
+    for (int b0 = 0; b0 < B && e == hipSuccess; b0 += chunk) {
+        const int nb = B - b0 < chunk ? B - b0 : chunk;
+        e = launch_onet_encode(ctx->d_w, ctx->oe, sel + (size_t)b0 * Tmax * 3, t_per_cloud ? t_per_cloud + b0 : nullptr, nb, Tmax,
+                               static_cast<float*>(ctx->ws_enc), c + (size_t)b0 * ONET_C, s);
+    }
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_onet_encode", e);
+}
+
+namespace {
+// CBN fold of B clouds into the context scratch: returns the device pointer of ab [B][11][2][256]
+hipError_t onet_fold(ifd_ctx* ctx, const float* c, int B, hipStream_t s, float** ab_out) {
+    const size_t per = (size_t)2 * ONET_NCBN * ONET_H;
+    hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, 2 * per * B * sizeof(float));
+    if (e != hipSuccess) return e;
+    float* gb = static_cast<float*>(ctx->ws_enc);
+    float* ab = gb + per * B;
+    *ab_out = ab;
+    return launch_onet_cbn(ctx->d_w, ctx->od, c, B, gb, ab, s);
+}
+}  // namespace
+
+int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, float* logits, float* dlogit_dp, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode: not an ONet context");
+    if (!c || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* ab = nullptr;
+    hipError_t e = onet_fold(ctx, c, B, s, &ab);
+    if (e == hipSuccess) e = launch_onet_decode(ctx->d_onet_img, ctx->d_onet_small, ab, p, B, K, logits, dlogit_dp, s);
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_onet_decode", e);
+}
+
+int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, const ifd_opt_params* prm,
+                      const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: not an ONet context");
+    if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 1024)");
+    if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
+    if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
+    OptArgs a{};
+    a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
+    a.knn_scan_every_step = prm->knn_scan_every_step;
+    a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
+    a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = ensure_ws(ctx, knn_list_bytes(B));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_optimize workspace", e);
+    float* ab = nullptr;
+    e = onet_fold(ctx, c, B, s, &ab);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), s);
+    if (e == hipSuccess)
+        e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
+                                 static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K, a, s);
+    return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_onet_optimize", e);
 }
 
 }  // extern "C"

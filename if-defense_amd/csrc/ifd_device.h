@@ -34,6 +34,12 @@ constexpr int OPT_THREADS = 512;     // 8 waves: 2 per SIMD (256 VGPRs each), tw
 constexpr float FIX_SCALE = 1099511627776.0f;        // 2^40: fixed-point scale of the neighbour scatter
 constexpr float FIX_INV = 1.0f / 1099511627776.0f;
 
+// ---- ONet-Opt variant (onet.hip): shipped config ONet/configs/onet_mn40.yaml ------------------------------
+constexpr int ONET_H = 256;          // decoder hidden size (onet/models/decoder.py:89)
+constexpr int ONET_C = 512;          // latent code (onet_mn40.yaml:18)
+constexpr int ONET_ENC_H = 512;      // encoder hidden size (onet_mn40.yaml:16-17)
+constexpr int ONET_NCBN = 11;        // bn_0 / bn_1 of 5 blocks + the final bn
+
 struct DecConst {
     float sdiv;      // (float)(1 + padding + 10e-6)           common.py:250
     float uclamp;    // (float)(1 - 10e-6)                     common.py:255

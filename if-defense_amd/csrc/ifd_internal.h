@@ -58,4 +58,25 @@ hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* gr
                             float h, float eps, hipStream_t s);
 hipError_t launch_normalize(float* p, int B, int K, hipStream_t s);
 
+// ---- ONet-Opt (onet.hip) --------------------------------------------------------------------------------
+// offsets (floats) into the canonical ONet weight vector (include/ifd.h order)
+struct OnetEncOffsets {
+    int pos_w, pos_b, fc0_w[5], fc0_b[5], fc1_w[5], fc1_b[5], sc_w[5], fcc_w, fcc_b;
+};
+struct OnetDecOffsets {
+    int cbn_gamma_w[11], cbn_gamma_b[11], cbn_beta_w[11], cbn_beta_b[11], cbn_mean[11], cbn_var[11], fc0_b[5];
+};
+hipError_t configure_onet_kernels();
+size_t onet_encode_ws_floats(int B, int Tmax);
+int onet_small_floats();
+hipError_t launch_onet_encode(const float* w, const OnetEncOffsets& eo, const float* sel, const int* t_per_cloud, int B,
+                              int Tmax, float* ws, float* c_out, hipStream_t s);
+hipError_t launch_onet_cbn(const float* w, const OnetDecOffsets& od, const float* c, int B, float* gb, float* ab,
+                           hipStream_t s);
+hipError_t launch_onet_decode(const float* img, const float* small, const float* ab, const float* p, int B, int K,
+                              float* logits, float* dlogit_dp, hipStream_t s);
+hipError_t launch_onet_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
+                                float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
+                                unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s);
+
 }  // namespace ifd

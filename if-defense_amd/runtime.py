@@ -55,6 +55,8 @@ class Restorer:
             self.ctx = self.lib.ifd_create(w.ctypes.data, w.size, C.byref(cfg), self.device.index or 0)
         if not self.ctx:
             raise IfdError((self.lib.ifd_last_error(None) or b"ifd_create failed").decode())
+        self._fn_decode, self._fn_optimize = self.lib.ifd_decode, self.lib.ifd_optimize
+        self.n_sel = 600                  # encoder subset (convonet_3plane_mn40.yaml:7 pointcloud_n)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -74,6 +76,10 @@ class Restorer:
     @staticmethod
     def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
         return None if t is None else t.data_ptr()
+
+    def _cond(self, c) -> torch.Tensor:
+        """The conditioning code in device layout (planes here; the latent code in OnetRestorer)."""
+        return self._planes(c)
 
     def _planes(self, c) -> torch.Tensor:
         if isinstance(c, dict):
@@ -161,13 +167,13 @@ class Restorer:
     # ---------------------------------------------------------------- call seams
     def decode(self, p: torch.Tensor, c, want_grad: bool = False):
         """generator.model.decode(p, c).logits -> [B,K]; with want_grad also d(sum logits)/dp [B,K,3]."""
-        planes = self._planes(c)
+        planes = self._cond(c)
         p = _f32(p, self.device)
         B, K = p.shape[:2]
         logits = torch.empty(B, K, device=self.device, dtype=torch.float32)
         grad = torch.empty(B, K, 3, device=self.device, dtype=torch.float32) if want_grad else None
         with torch.cuda.device(self.device):
-            self._check(self.lib.ifd_decode(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, logits.data_ptr(),
+            self._check(self._fn_decode(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, logits.data_ptr(),
                                             self._ptr(grad), self._stream()))
         return (logits, grad) if want_grad else logits
 
@@ -197,7 +203,7 @@ class Restorer:
         Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
         is left to the caller.
         """
-        planes = self._planes(c)
+        planes = self._cond(c)
         p = _f32(opt_points, self.device).clone()
         B, K = p.shape[:2]
         n_steps = int(iterations) + 1 if steps is None else int(steps)
@@ -218,7 +224,7 @@ class Restorer:
                            float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12,
                            int(bool(knn_scan_every_step)))
         with torch.cuda.device(self.device):
-            self._check(self.lib.ifd_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
+            self._check(self._fn_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
                                               self._ptr(lb_arr), self._ptr(m), self._ptr(v), self._ptr(loss),
                                               self._stream()))
         out = (p,)
@@ -243,3 +249,49 @@ class Restorer:
             self._check(self.lib.ifd_normalize_unit_sphere(self.ctx, p.data_ptr(), p.shape[0], p.shape[1],
                                                            self._stream()))
         return p
+
+
+class OnetRestorer(Restorer):
+    """ONet-Opt (ONet/opt_defense.py): same call seams, Occupancy-Network model (ifd_onet_create).
+
+    ``encode_inputs`` returns the latent code c [B,512] (generator.model.encode_inputs, :300); ``decode`` and
+    ``optimize_points`` take it where ConvONet takes the planes (z is empty: z_dim 0 in configs/onet_mn40.yaml)."""
+
+    def __init__(self, weights: np.ndarray, device=None, threshold: float = 0.2):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise IfdError("no GPU visible: the restoration path only runs on an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise IfdError("OnetRestorer needs a cuda (ROCm) device, got %s" % self.device)
+        self.threshold = float(threshold)
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        if w.size != self.lib.ifd_onet_weight_count():
+            raise IfdError("expected %d weights, got %d" % (self.lib.ifd_onet_weight_count(), w.size))
+        with torch.cuda.device(self.device):
+            self.ctx = self.lib.ifd_onet_create(w.ctypes.data, w.size, self.device.index or 0)
+        if not self.ctx:
+            raise IfdError((self.lib.ifd_last_error(None) or b"ifd_onet_create failed").decode())
+        self._fn_decode, self._fn_optimize = self.lib.ifd_onet_decode, self.lib.ifd_onet_optimize
+        self.n_sel = 300                  # onet_mn40.yaml:6 pointcloud_n
+
+    def _cond(self, c) -> torch.Tensor:
+        c = _f32(c, self.device)
+        if c.dim() != 2 or c.shape[1] != 512:
+            raise IfdError("the ONet conditioning code must be [B,512]")
+        return c
+
+    def encode_inputs(self, sel: torch.Tensor, t_per_cloud: Optional[torch.Tensor] = None) -> torch.Tensor:
+        sel = _f32(sel, self.device)
+        B, T = sel.shape[:2]
+        tpc = None if t_per_cloud is None else t_per_cloud.to(device=self.device, dtype=torch.int32).contiguous()
+        c = torch.empty(B, 512, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_onet_encode(self.ctx, sel.data_ptr(), self._ptr(tpc), B, T, c.data_ptr(),
+                                                 self._stream()))
+        return c
+
+    def encode_points(self, *a, **k):
+        raise IfdError("encode_points / unet belong to the ConvONet model")
+
+    unet = encode_points

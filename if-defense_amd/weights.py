@@ -45,11 +45,35 @@ def canonical_keys() -> List[Tuple[str, Tuple[int, ...]]]:
     return k
 
 
-def pack_state_dict(state: Dict[str, object]) -> np.ndarray:
+def onet_canonical_keys() -> List[Tuple[str, Tuple[int, ...]]]:
+    """ONet-Opt (ONet/configs/onet_mn40.yaml): the reference checkpoint's state_dict order without the BatchNorm
+    ``num_batches_tracked`` scalars (include/ifd.h, ONet section).  Conv1d kernels keep their trailing 1."""
+    k: List[Tuple[str, Tuple[int, ...]]] = [("decoder.fc_p.weight", (256, 3, 1)), ("decoder.fc_p.bias", (256,))]
+
+    def cbn(pre):
+        return [(pre + ".conv_gamma.weight", (256, 512, 1)), (pre + ".conv_gamma.bias", (256,)),
+                (pre + ".conv_beta.weight", (256, 512, 1)), (pre + ".conv_beta.bias", (256,)),
+                (pre + ".bn.running_mean", (256,)), (pre + ".bn.running_var", (256,))]
+
+    for i in range(5):
+        k += cbn(f"decoder.block{i}.bn_0") + cbn(f"decoder.block{i}.bn_1")
+        k += [(f"decoder.block{i}.fc_0.weight", (256, 256, 1)), (f"decoder.block{i}.fc_0.bias", (256,)),
+              (f"decoder.block{i}.fc_1.weight", (256, 256, 1)), (f"decoder.block{i}.fc_1.bias", (256,))]
+    k += cbn("decoder.bn") + [("decoder.fc_out.weight", (1, 256, 1)), ("decoder.fc_out.bias", (1,))]
+    k += [("encoder.fc_pos.weight", (1024, 3)), ("encoder.fc_pos.bias", (1024,))]
+    for i in range(5):
+        k += [(f"encoder.block_{i}.fc_0.weight", (512, 1024)), (f"encoder.block_{i}.fc_0.bias", (512,)),
+              (f"encoder.block_{i}.fc_1.weight", (512, 512)), (f"encoder.block_{i}.fc_1.bias", (512,)),
+              (f"encoder.block_{i}.shortcut.weight", (512, 1024))]
+    k += [("encoder.fc_c.weight", (512, 512)), ("encoder.fc_c.bias", (512,))]
+    return k
+
+
+def pack_state_dict(state: Dict[str, object], model: str = "convonet") -> np.ndarray:
     """Flatten a state_dict (torch tensors or numpy arrays) into one float32 vector.  Missing or
     mis-shaped tensors raise KeyError / ValueError, like ``load_state_dict(strict=True)``."""
     parts = []
-    for name, shape in canonical_keys():
+    for name, shape in (onet_canonical_keys() if model == "onet" else canonical_keys()):
         if name not in state:
             raise KeyError("checkpoint lacks %r" % name)
         t = state[name]
@@ -60,14 +84,14 @@ def pack_state_dict(state: Dict[str, object]) -> np.ndarray:
     return np.concatenate(parts)
 
 
-def load_checkpoint(path: str) -> np.ndarray:
+def load_checkpoint(path: str, model: str = "convonet") -> np.ndarray:
     """``torch.load`` a reference checkpoint (ConvONet/opt_defense.py:65) and pack it.  Accepts a bare
     state_dict or the training checkpoints' {'model': state_dict, ...} wrapper."""
     import torch
     sd = torch.load(path, map_location="cpu")
     if isinstance(sd, dict) and "model" in sd and "decoder.fc_p.weight" not in sd:
         sd = sd["model"]
-    return pack_state_dict(sd)
+    return pack_state_dict(sd, model)
 
 
 def random_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
@@ -118,4 +142,42 @@ def random_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
         conv(f"encoder.unet.up_convs.{i}.conv2", c_out, c_out, 3)
         c_in = c_out
     conv("encoder.unet.conv_final", 32, c_in, 1)
+    return w
+
+
+def onet_random_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random ONet weights (same streams as the test oracle's: Linear / 1x1-conv U(+-1/sqrt(fan_in)); what
+    the reference zero-initialises - fc_1, CBN gamma/beta convs - is randomised; non-trivial BatchNorm statistics)."""
+    rng = np.random.default_rng(seed + 7001)
+    w: Dict[str, np.ndarray] = {}
+
+    def lin(key, n_out, n_in, bias=True, conv=False, scale=1.0):
+        b = scale / np.sqrt(n_in)
+        shape = (n_out, n_in, 1) if conv else (n_out, n_in)
+        w[key + ".weight"] = rng.uniform(-b, b, size=shape).astype(np.float32)
+        if bias:
+            w[key + ".bias"] = rng.uniform(-b, b, size=(n_out,)).astype(np.float32)
+
+    lin("encoder.fc_pos", 1024, 3)
+    for i in range(5):
+        lin(f"encoder.block_{i}.fc_0", 512, 1024)
+        lin(f"encoder.block_{i}.fc_1", 512, 512)
+        lin(f"encoder.block_{i}.shortcut", 512, 1024, bias=False)
+    lin("encoder.fc_c", 512, 512)
+
+    def cbn(key):
+        lin(key + ".conv_gamma", 256, 512, conv=True, scale=8.0)
+        w[key + ".conv_gamma.bias"] = (1.0 + rng.uniform(-0.2, 0.2, 256)).astype(np.float32)
+        lin(key + ".conv_beta", 256, 512, conv=True, scale=8.0)
+        w[key + ".bn.running_mean"] = rng.normal(0.0, 0.3, 256).astype(np.float32)
+        w[key + ".bn.running_var"] = rng.uniform(0.5, 1.5, 256).astype(np.float32)
+
+    lin("decoder.fc_p", 256, 3, conv=True)
+    for i in range(5):
+        cbn(f"decoder.block{i}.bn_0")
+        cbn(f"decoder.block{i}.bn_1")
+        lin(f"decoder.block{i}.fc_0", 256, 256, conv=True)
+        lin(f"decoder.block{i}.fc_1", 256, 256, conv=True)
+    cbn("decoder.bn")
+    lin("decoder.fc_out", 1, 256, conv=True)
     return w

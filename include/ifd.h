@@ -184,13 +184,55 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
  * to HOST memory; synchronises the device.  [0] wave-level neighbour-list rebuilds, [1] wave-level certificate
  * failures served by the exact brute-force scan, [2] extra wave-level rebuild work (exact scans for the list
  * radii + re-passes for overflowed balls), [3] shader-clock cycles cloud 0 spent in the optimiser kernel
- * (effective clock = cycles / kernel time), [4] wave-steps that had to evaluate the back ring of the lists.
- * n <= IFD_N_COUNTERS. */
+ * (effective clock = cycles / kernel time), [4] wave-steps that had to evaluate the back ring of the lists,
+ * [5] wave-steps on the exact insertion path (near-ties, loss-reporting step), [6] wave-steps with individual
+ * list refreshes, [7] lists built in total.  n <= IFD_N_COUNTERS. */
 #define IFD_N_COUNTERS 16
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
 
 /* normalize_batch_pc (ConvONet/opt_defense.py:76-83) in place on p [B,K,3]. */
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ONet-Opt variant (ONet/opt_defense.py; BASELINE config #1).
+ *
+ * Same restoration loop with the Occupancy-Network model of ONet/configs/onet_mn40.yaml: encoder
+ * ResnetPointnet(c_dim 512, hidden 512) on pointcloud_n = 300 points, decoder DecoderCBatchNorm(z_dim 0, c_dim 512,
+ * hidden 256) in eval mode.  `diff ConvONet/opt_defense.py ONet/opt_defense.py` is the config path, the
+ * decode(p, z, c) call (:212) and the save name, so ifd_sor / ifd_prepare (n_sel = 300) / ifd_repulsion /
+ * ifd_normalize_unit_sphere / ifd_get_counters serve both kinds of context; the entry points below replace
+ * ifd_encode_planes / ifd_decode / ifd_optimize, with the latent code c [B,512] in place of the planes (z is empty).
+ *
+ * Canonical weight order = the reference checkpoint's state_dict order (ONet `pretrain/onet.pth`) without the
+ * BatchNorm num_batches_tracked scalars, every tensor row-major float32, Conv1d kernels squeezed:
+ *   decoder.fc_p.{weight[256,3],bias}; for i in 0..4: decoder.block{i}.bn_0.{conv_gamma.weight[256,512],
+ *   conv_gamma.bias, conv_beta.weight[256,512], conv_beta.bias, bn.running_mean, bn.running_var},
+ *   decoder.block{i}.bn_1.{same six}, decoder.block{i}.fc_0.{weight[256,256],bias}, decoder.block{i}.fc_1.{weight,
+ *   bias}; decoder.bn.{same six}; decoder.fc_out.{weight[256],bias[1]};
+ *   encoder.fc_pos.{weight[1024,3],bias}; for i in 0..4: encoder.block_{i}.{fc_0.weight[512,1024], fc_0.bias,
+ *   fc_1.weight[512,512], fc_1.bias, shortcut.weight[512,1024]}; encoder.fc_c.{weight[512,512],bias}
+ *   (10,379,521 floats). */
+#define IFD_MODEL_CONVONET 0
+#define IFD_MODEL_ONET 1
+size_t ifd_onet_weight_count(void);
+
+/* config.get_model + load_state_dict + model.eval() (ONet/opt_defense.py:64-73).  NULL on failure
+ * (ifd_last_error(NULL)). */
+ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device);
+
+/* generator.model.encode_inputs(x) (ONet/opt_defense.py:300; im2mesh/encoder/pointnet.py:86-113):
+ * sel [B,Tmax,3] (+ optional t_per_cloud [B]: valid points per cloud) -> c [B,512]. */
+int ifd_onet_encode(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* c,
+                    void* stream);
+
+/* generator.model.decode(p, z, c).logits (ONet/opt_defense.py:212; onet/models/decoder.py:115-133):
+ * c [B,512], p [B,K,3] -> logits [B,K]; dlogit_dp (optional) [B,K,3] = d(sum of logits)/dp. */
+int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, float* logits,
+                    float* dlogit_dp, void* stream);
+
+/* optimize_points (ONet/opt_defense.py:182-239); arguments as ifd_optimize with c [B,512] for the planes. */
+int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, const ifd_opt_params* prm,
+                      const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream);
 
 #ifdef __cplusplus
 }

@@ -474,3 +474,78 @@ def test_full_size_properties(restorer):
     lo = I.defend_point_cloud(restorer, clouds[:1234], args, cloud_index_base=0, total_clouds=2468)
     hi = I.defend_point_cloud(restorer, clouds[1234:], args, cloud_index_base=1234, total_clouds=2468)
     assert np.array_equal(np.concatenate([lo, hi]), full)
+
+
+# ------------------------------------------------------------------------------------------------
+# ONet-Opt variant (BASELINE config #1): encoder / decoder / optimiser through ifd_onet_* against the fixtures
+# generated from the reference's ONet modules and against the ONet oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def og():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onet_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def onet():
+    import ifdefense_amd as I
+    r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device="cuda:0")
+    yield r
+    r.close()
+
+
+def test_onet_encoder_latent_code(onet, og):
+    c = onet.encode_inputs(torch.from_numpy(og["sel"])).cpu().numpy()
+    assert _rel(c, og["c"]) < 1e-5
+    # ragged: a shorter cloud in a padded batch == that cloud alone
+    sel = torch.from_numpy(og["sel"]).clone()
+    sel[1, 200:] = 0
+    a = onet.encode_inputs(sel, torch.tensor([300, 200, 300, 300]))
+    b = onet.encode_inputs(sel[1:2, :200])
+    assert torch.equal(a[1], b[0])
+
+
+def test_onet_decode_logits_and_input_gradient(onet, og, golden):
+    p = torch.from_numpy(golden["init_points"][:2])
+    logits, grad = onet.decode(p, torch.from_numpy(og["c"][:2]), want_grad=True)
+    assert _rel(logits.cpu().numpy(), og["dec_logits"]) < 1e-5
+    # 22 ReLUs x 256 channels per point: a pre-activation within rounding of 0 flips one mask bit (CBN is folded to
+    # a x + b here, (x - mean) / sqrt(var + eps) * gamma + beta in the reference) - count such points, bound the rest
+    dg = np.abs(grad.cpu().numpy() - og["dec_dlogit_dp"]).max(-1) / np.abs(og["dec_dlogit_dp"]).max()
+    assert (dg > 1e-4).sum() <= 3 and dg.max() < 2e-2 and np.median(dg) < 1e-6, (dg.max(), (dg > 1e-4).sum())
+    assert torch.equal(onet.decode(p, torch.from_numpy(og["c"][:2])), logits)
+    for K in (1, 17, 129, 1000):                                  # ragged point counts
+        got = onet.decode(p[:, :K], torch.from_numpy(og["c"][:2])).cpu().numpy()
+        assert got.shape == (2, K) and _rel(got, og["dec_logits"][:, :K]) < 1e-5, K
+
+
+def test_onet_p1_teacher_forced_and_p2_free_running(onet, og):
+    c = torch.from_numpy(og["c"][:2])
+    for t in (0, 1, 9):
+        x = torch.from_numpy(og[f"traj{t}_x"])
+        state = (torch.from_numpy(og[f"traj{t}_m"]), torch.from_numpy(og[f"traj{t}_v"]), t)
+        out = onet.optimize_points(x, c, rep_weight=500.0, steps=1, state=state, normalize=False)
+        d = np.abs(out.cpu().numpy() - og[f"traj{t}_x_next"])
+        assert (d > 1e-6).mean() < 2e-3, (t, float(d.max()), int((d > 1e-6).sum()))
+    x10 = onet.optimize_points(torch.from_numpy(og["traj0_x"]), c, rep_weight=500.0, steps=10, normalize=False)
+    d10 = np.linalg.norm(x10.cpu().numpy() - og["traj9_x_next"], axis=-1)
+    print("ONet P2: 10 steps max %.2e" % d10.max())
+    assert d10.max() < 1e-3
+    _, loss = onet.optimize_points(torch.from_numpy(og["traj0_x"]), c, rep_weight=500.0, steps=1, normalize=False,
+                                   return_loss=True)
+    loss = loss.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(loss[:, 0].sum() / 2, og["traj0_loss"][0], rtol=1e-5)
+    np.testing.assert_allclose(loss[:, 1].mean() * 500.0, og["traj0_loss"][1], rtol=1e-5)
+
+
+def test_onet_end_to_end_and_sharding(onet, og, golden):
+    init = torch.from_numpy(golden["init_points"])
+    c = torch.from_numpy(og["c"])
+    out = onet.optimize_points(init, c, rep_weight=500.0, iterations=10)
+    d = np.linalg.norm(out.cpu().numpy() - og["e2e10_out"], axis=-1)
+    assert d.max() < 1e-3, d.max()
+    lo = onet.optimize_points(init[:1], c[:1], rep_weight=500.0, iterations=10, loss_batch=4)
+    hi = onet.optimize_points(init[1:], c[1:], rep_weight=500.0, iterations=10, loss_batch=4)
+    assert torch.equal(torch.cat([lo, hi]), out)                  # P4: shard-and-concatenate is bitwise
+    with pytest.raises(Exception):
+        onet.encode_points(torch.zeros(1, 300, 3))
