@@ -22,9 +22,10 @@ def str2bool(v):
     return v.lower() in ("yes", "true", "t", "1")
 
 
-def build_parser():
+def build_parser(model="convonet"):
     parser = argparse.ArgumentParser(description='Extract meshes from occupancy process.')
-    parser.add_argument('--config', type=str, default='configs/convonet_3plane_mn40.yaml', help='Path to config file.')
+    parser.add_argument('--config', type=str, help='Path to config file.',
+                        default='configs/onet_mn40.yaml' if model == "onet" else 'configs/convonet_3plane_mn40.yaml')
     parser.add_argument('--sample_npoint', type=int, default=1024, help='Re-sample points number per mesh.')
     parser.add_argument('--padding_scale', type=float, default=0.9,
                         help='Used in pre-processing point clouds, padding in unit cube')
@@ -56,6 +57,16 @@ DEFAULT_CFG = {
 }
 
 
+# ONet-Opt (ONet/opt_defense.py): resolved values of ONet/configs/onet_mn40.yaml over configs/default.yaml
+DEFAULT_CFG_ONET = {
+    'method': 'onet',
+    'data': {'pointcloud_n': 300, 'dim': 3},
+    'model': {'encoder': 'pointnet_resnet', 'decoder': 'cbatchnorm', 'encoder_latent': None, 'c_dim': 512, 'z_dim': 0,
+              'encoder_kwargs': {'hidden_dim': 512}, 'decoder_kwargs': {}},
+    'test': {'threshold': 0.2, 'model_file': 'pretrain/onet.pth'},
+}
+
+
 def _merge(dst, src):
     for k, v in src.items():
         if isinstance(v, dict) and isinstance(dst.get(k), dict):
@@ -64,16 +75,17 @@ def _merge(dst, src):
             dst[k] = v
 
 
-def load_config(path, default_path=None):
+def load_config(path, default_path=None, model="convonet"):
     """src/config.py:11-38 (inherit_from / default merge) with yaml.safe_load (the reference's bare yaml.load
     raises on PyYAML >= 6)."""
+    DEFAULT_CFG = DEFAULT_CFG_ONET if model == "onet" else globals()["DEFAULT_CFG"]
     if not os.path.exists(path):
         return DEFAULT_CFG
     with open(path) as f:
         special = yaml.safe_load(f) or {}
     inherit = special.get('inherit_from')
     if inherit is not None:
-        cfg = load_config(inherit, default_path)
+        cfg = load_config(inherit, default_path, model)
     elif default_path is not None and os.path.exists(default_path):
         with open(default_path) as f:
             cfg = yaml.safe_load(f) or {}
@@ -85,8 +97,17 @@ def load_config(path, default_path=None):
     return base
 
 
-def check_supported(cfg):
-    m, ek = cfg['model'], cfg['model'].get('encoder_kwargs', {})
+def check_supported(cfg, model="convonet"):
+    m, ek = cfg['model'], cfg['model'].get('encoder_kwargs', {}) or {}
+    if model == "onet":
+        ok = (m.get('encoder') == 'pointnet_resnet' and m.get('decoder') == 'cbatchnorm' and m.get('c_dim') == 512 and
+              m.get('z_dim') == 0 and ek.get('hidden_dim') == 512 and
+              (m.get('decoder_kwargs') or {}).get('hidden_size', 256) == 256 and
+              not (m.get('decoder_kwargs') or {}).get('legacy', False))
+        if not ok:
+            raise SystemExit("unsupported model config: only the shipped Occupancy Network "
+                             "(configs/onet_mn40.yaml: pointnet_resnet 512 / cbatchnorm 256, z_dim 0) is built for MI355X")
+        return
     ok = (m.get('encoder') == 'pointnet_local_pool' and m.get('decoder') == 'simple_local' and m.get('c_dim') == 32 and
           ek.get('hidden_dim') == 32 and ek.get('plane_resolution') == 64 and
           sorted(ek.get('plane_type', [])) == ['xy', 'xz', 'yz'] and ek.get('unet') and
@@ -98,20 +119,25 @@ def check_supported(cfg):
                          "(configs/convonet_3plane_mn40.yaml) is built for MI355X")
 
 
-def main(argv=None):
-    args = build_parser().parse_args(argv)
-    cfg = load_config(args.config, 'configs/default.yaml')
-    check_supported(cfg)
+def main(argv=None, model="convonet"):
+    """model = "convonet": ConvONet/opt_defense.py; "onet": ONet/opt_defense.py (python -m ifdefense_amd.onet_opt_defense)."""
+    args = build_parser(model).parse_args(argv)
+    cfg = load_config(args.config, 'configs/default.yaml', model)
+    check_supported(cfg, model)
 
     import torch
-    from . import DefenseArgs, Restorer, defend_npz_test_data, defend_npz_train_test_data, defend_point_cloud, weights
+    from . import (DefenseArgs, OnetRestorer, Restorer, defend_npz_test_data, defend_npz_train_test_data,
+                   defend_point_cloud, weights)
     from . import dist as D
 
     rank, world, local = D.init_from_env()
     device = torch.device('cuda', local)
     wpath = args.weights or cfg['test']['model_file']
-    r = Restorer(weights.load_checkpoint(wpath), device=device, padding=cfg['data'].get('padding', 0.1),
-                 threshold=cfg['test']['threshold'])
+    if model == "onet":
+        r = OnetRestorer(weights.load_checkpoint(wpath, "onet"), device=device, threshold=cfg['test']['threshold'])
+    else:
+        r = Restorer(weights.load_checkpoint(wpath), device=device, padding=cfg['data'].get('padding', 0.1),
+                     threshold=cfg['test']['threshold'])
     dargs = DefenseArgs(sample_npoint=args.sample_npoint, padding_scale=args.padding_scale, init_sigma=args.init_sigma,
                         iterations=args.iterations, batch_size=args.batch_size, lr=args.lr, rep_weight=args.rep_weight,
                         sor=args.sor, sor_k=args.sor_k, sor_alpha=args.sor_alpha, threshold=cfg['test']['threshold'],

@@ -66,12 +66,12 @@ def defend_point_cloud(r: Restorer, pc, args: DefenseArgs, cloud_index_base: int
     return out if return_device else out.cpu().numpy()
 
 
-def get_save_name(path: str) -> str:
-    """opt_defense.py:242-252: <dir>/ConvONet-Opt/convonet_opt-<basename>."""
+def get_save_name(path: str, model: str = "convonet") -> str:
+    """opt_defense.py:242-252: <dir>/ConvONet-Opt/convonet_opt-<basename> (ONet/opt_defense.py: ONet-Opt/onet_opt-)."""
     sub = path.split('/')
-    folder = os.path.join(path[:path.rindex(sub[-1])], 'ConvONet-Opt')
+    folder = os.path.join(path[:path.rindex(sub[-1])], 'ONet-Opt' if model == "onet" else 'ConvONet-Opt')
     os.makedirs(folder, exist_ok=True)
-    return os.path.join(folder, 'convonet_opt-' + sub[-1])
+    return os.path.join(folder, ('onet_opt-' if model == "onet" else 'convonet_opt-') + sub[-1])
 
 
 def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None) -> str:
@@ -82,7 +82,7 @@ def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None)
     target_label = npz['target_label'] if 'target_label' in npz.files else None
     fn = defend or (lambda a: defend_point_cloud(r, a, args))
     out = fn(test_pc)
-    save_path = get_save_name(path)
+    save_path = get_save_name(path, getattr(r, 'model_name', 'convonet'))
     kw = dict(test_pc=out.astype(np.float32), test_label=test_label.astype(np.uint8))
     if target_label is not None:
         kw['target_label'] = target_label.astype(np.uint8)
@@ -97,7 +97,7 @@ def defend_npz_train_test_data(r: Restorer, path: str, args: DefenseArgs, defend
     fn = defend or (lambda a: defend_point_cloud(r, a, args))
     def_train = fn(npz['train_pc'][..., :3])
     def_test = fn(npz['test_pc'][..., :3])
-    save_path = get_save_name(path)
+    save_path = get_save_name(path, getattr(r, 'model_name', 'convonet'))
     np.savez(save_path, train_pc=def_train.astype(np.float32), train_label=npz['train_label'].astype(np.uint8),
              test_pc=def_test.astype(np.float32), test_label=npz['test_label'].astype(np.uint8))
     print('defense result saved to {}'.format(save_path))

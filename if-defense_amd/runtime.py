@@ -38,6 +38,7 @@ def _f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
 
 class Restorer:
     """One context = one model on one GPU (ifd_create ... ifd_destroy)."""
+    model_name = "convonet"
 
     def __init__(self, weights: np.ndarray, device=None, padding: float = 0.1, threshold: float = 0.2):
         self.lib = _lib.load()
@@ -256,6 +257,7 @@ class OnetRestorer(Restorer):
 
     ``encode_inputs`` returns the latent code c [B,512] (generator.model.encode_inputs, :300); ``decode`` and
     ``optimize_points`` take it where ConvONet takes the planes (z is empty: z_dim 0 in configs/onet_mn40.yaml)."""
+    model_name = "onet"
 
     def __init__(self, weights: np.ndarray, device=None, threshold: float = 0.2):
         self.lib = _lib.load()

@@ -549,3 +549,58 @@ def test_onet_end_to_end_and_sharding(onet, og, golden):
     assert torch.equal(torch.cat([lo, hi]), out)                  # P4: shard-and-concatenate is bitwise
     with pytest.raises(Exception):
         onet.encode_points(torch.zeros(1, 300, 3))
+
+
+def test_onet_config1_pipeline_16_clouds(onet):
+    """BASELINE config #1: ONet-Opt on 16 clean 1024-point clouds, 50 iterations - the whole driver
+    (SOR -> preprocess / 300-point subset -> encoder -> init -> optimiser -> normalise) against the oracle fed
+    with the same draws, plus sharding invariance."""
+    from oracle import convonet_oracle as CO
+    from oracle import onet_oracle as OO
+    import bench
+    import ifdefense_amd as I
+    ow = OO.to_torch(OO.make_random_weights(0))
+    clouds = bench.synth_clouds(16)
+    x = torch.from_numpy(clouds).cuda()
+    keep = onet.sor(x)
+    ref_keep, _ = CO.sor_keep_mask(torch.from_numpy(clouds))
+    assert np.array_equal(keep.cpu().numpy().astype(bool), ref_keep.numpy().astype(bool))
+    prep = onet.prepare(x, keep, n_sel=300, seed=21)
+    assert prep["t_per_cloud"].cpu().tolist() == [300] * 16
+    c = onet.encode_inputs(prep["sel"], prep["t_per_cloud"])
+    c_ref = OO.encode_latent(ow, prep["sel"].cpu())
+    assert _rel(c.cpu().numpy(), c_ref.numpy()) < 1e-5
+    hip = onet.optimize_points(prep["init"], c, rep_weight=500.0, iterations=9).cpu().numpy()
+    ref = OO.optimize_points(ow, prep["init"].cpu(), c_ref, rep_weight=500.0, iterations=9).numpy()
+    d = np.linalg.norm(hip - ref, axis=-1)
+    print("ONet config #1, 10 steps, 16 clouds: max %.2e median %.2e, points > 1e-3: %d of %d" %
+          (d.max(), np.median(d), (d > 1e-3).sum(), d.size))
+    assert (d > 1e-3).mean() < 1e-3 and np.median(d) < 1e-5
+    args = I.DefenseArgs(iterations=50, input_npoint=300, seed=21)
+    full = I.defend_point_cloud(onet, clouds, args)
+    assert full.shape == (16, 1024, 3) and np.isfinite(full).all()
+    np.testing.assert_allclose(np.linalg.norm(full, axis=-1).max(axis=1), 1.0, rtol=1e-6)
+    lo = I.defend_point_cloud(onet, clouds[:5], args, cloud_index_base=0, total_clouds=16)
+    hi = I.defend_point_cloud(onet, clouds[5:], args, cloud_index_base=5, total_clouds=16)
+    assert np.array_equal(np.concatenate([lo, hi]), full)
+
+
+def test_onet_cli_end_to_end(tmp_path):
+    """python -m ifdefense_amd.onet_opt_defense: ONet/opt_defense.py's output location / keys / dtypes."""
+    import subprocess, sys, os
+    import ifdefense_amd as I
+    wpath = tmp_path / "onet.pth"
+    sd = {k: torch.from_numpy(v) for k, v in I.weights.onet_random_state_dict(0).items()}
+    sd["decoder.bn.bn.num_batches_tracked"] = torch.tensor(7)                      # present in real checkpoints, ignored
+    torch.save(sd, wpath)
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "convonet_golden.npz")))
+    src = tmp_path / "clean.npz"
+    np.savez(src, test_pc=g["raw"], test_label=np.array([0, 8, 30, 39]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "ifdefense_amd.onet_opt_defense", "--data_root", str(src), "--iterations=10",
+                        "--weights", str(wpath)], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(tmp_path / "ONet-Opt" / "onet_opt-clean.npz")
+    assert sorted(z.files) == ["test_label", "test_pc"]
+    assert z["test_pc"].shape == (4, 1024, 3) and z["test_pc"].dtype == np.float32 and z["test_label"].dtype == np.uint8
+    np.testing.assert_allclose(np.linalg.norm(z["test_pc"], axis=-1).max(axis=1), 1.0, rtol=1e-6)

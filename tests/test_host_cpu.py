@@ -38,6 +38,26 @@ def test_config_loading(tmp_path):
         od.check_supported(bad)
 
 
+def test_onet_cli_config_and_save_name(tmp_path):
+    """ONet/opt_defense.py differs from ConvONet's in the default config, the model and the save name only."""
+    import ifdefense_amd as I
+    from ifdefense_amd import opt_defense as od
+    a = od.build_parser("onet").parse_args([])
+    assert a.config == 'configs/onet_mn40.yaml' and a.iterations == 200 and a.batch_size == 192      # ONet/opt_defense.py:24-53
+    cfg = od.load_config(str(tmp_path / "missing.yaml"), None, "onet")
+    assert cfg['data']['pointcloud_n'] == 300 and cfg['test']['threshold'] == 0.2 and cfg['model']['z_dim'] == 0
+    od.check_supported(cfg, "onet")
+    with pytest.raises(SystemExit):
+        od.check_supported({**cfg, 'model': {**cfg['model'], 'z_dim': 64}}, "onet")
+    assert I.get_save_name(str(tmp_path / "x.npz"), "onet") == str(tmp_path / "ONet-Opt" / "onet_opt-x.npz")
+    keys = I.weights.onet_canonical_keys()
+    assert sum(int(np.prod(s)) for _, s in keys) == 10379521 and keys[0][0] == "decoder.fc_p.weight"
+    sd = I.weights.onet_random_state_dict(1)
+    assert I.weights.pack_state_dict(sd, "onet").size == 10379521
+    with pytest.raises(KeyError):
+        I.weights.pack_state_dict({k: v for k, v in sd.items() if k != "encoder.fc_c.bias"}, "onet")
+
+
 def test_save_name_and_npz_schema(tmp_path):
     import ifdefense_amd as I
     src = tmp_path / "kNN-pointnet.npz"
