@@ -112,7 +112,7 @@ def subsample_like(clouds, k=256, seed=1234):
     return np.stack([c[np.sort(rng.choice(len(c), k, replace=False))] for c in clouds]).astype(np.float32)
 
 
-def cpu_baseline(clouds, n_sample=16, budget_s=15.0):
+def cpu_baseline(clouds, n_sample=16, budget_s=15.0, onet=False):
     """The CPU oracle (a port of the reference's op sequence: bmm-kNN + topk, autograd, torch.optim.Adam) timed
     on the host cores on a bounded sample, scaled to 501 steps.  Reported next to the GPU number, not a target.
     Threads are capped at 16: with one thread per core of a 256-core host the small ops of this loop run
@@ -120,25 +120,29 @@ def cpu_baseline(clouds, n_sample=16, budget_s=15.0):
     from oracle import convonet_oracle as O
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
-    w = O.to_torch(O.make_random_weights(0))
+    if onet:
+        from oracle import onet_oracle as OO
+        MO, w, n_in, encode = OO, OO.to_torch(OO.make_random_weights(0)), 300, OO.encode_latent
+    else:
+        MO, w, n_in, encode = O, O.to_torch(O.make_random_weights(0)), 600, O.encode_inputs
     x = torch.from_numpy(clouds[:n_sample])
     rng = np.random.default_rng(0)
     t0 = time.perf_counter()
     keep, _ = O.sor_keep_mask(x)
     proc = [O.preprocess_pc(clouds[b][keep[b].numpy()]) for b in range(n_sample)]
-    sel = torch.from_numpy(np.stack([p[rng.choice(len(p), 600, replace=False)] for p in proc]))
+    sel = torch.from_numpy(np.stack([p[rng.choice(len(p), n_in, replace=False)] for p in proc]))
     with torch.no_grad():
-        planes = O.encode_inputs(w, sel)
+        planes = encode(w, sel)
     idx = np.stack([rng.integers(0, len(p), K_POINTS) for p in proc])
     init = O.init_points(proc, idx, rng.standard_normal((n_sample, K_POINTS, 3)).astype(np.float32))
     t_pre = time.perf_counter() - t0
-    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=0, normalize=False)       # warm-up step
+    MO.optimize_points(w, init, planes, rep_weight=500.0, iterations=0, normalize=False)      # warm-up step
     t0 = time.perf_counter()
-    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=1, normalize=False)       # 2-step probe
+    MO.optimize_points(w, init, planes, rep_weight=500.0, iterations=1, normalize=False)      # 2-step probe
     probe = (time.perf_counter() - t0) / 2
     n_steps = int(max(3, min(50, budget_s / max(probe, 1e-3))))
     t0 = time.perf_counter()
-    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=n_steps - 1, normalize=True)
+    MO.optimize_points(w, init, planes, rep_weight=500.0, iterations=n_steps - 1, normalize=True)
     t_opt = time.perf_counter() - t0
     per_cloud = (t_pre + t_opt / n_steps * (ITERATIONS + 1)) / n_sample
     return {"value": round(1.0 / per_cloud, 4), "unit": "clouds/s", "cores": threads, "kind": "port",
@@ -153,7 +157,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clouds", type=int, default=N_CLOUDS, help="clouds per GPU per step (default: MN40 test size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("convonet-opt", "onet-opt"), default="convonet-opt",
+                    help="convonet-opt = the BASELINE metric (default); onet-opt = the ONet-Opt decoder variant "
+                         "(BASELINE config #1 model, SURVEY N4) at 500 iterations - an extra line, not the headline")
     a = ap.parse_args()
+    onet = a.workload == "onet-opt"
+    if onet and a.clouds == N_CLOUDS:
+        a.clouds = 256                                                  # one cloud per CU; ~3 s per step
 
     import ifdefense_amd as I
     from ifdefense_amd import dist as D
@@ -169,8 +179,14 @@ def main():
     all_clouds = synth_clouds(total)
     lo, hi, per = D.shard_range(total, rank, world)
     x = torch.from_numpy(all_clouds[lo:hi]).to(dev)                     # resident in HBM before timing
-    r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device=dev)
-    args = I.DefenseArgs(iterations=ITERATIONS, seed=1234)
+    if onet:
+        r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device=dev)
+        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234, input_npoint=300)
+        flop_per_cloud = 2 * 2 * (10 * 256 * 256 + 4 * 256) * K_POINTS * (ITERATIONS + 1)     # 1.347 TFLOP
+    else:
+        r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device=dev)
+        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234)
+        flop_per_cloud = FLOP_DENSE_PER_CLOUD
 
     # time the dominant kernel (the persistent optimiser) with events on the stream it is launched on
     ev = []
@@ -216,29 +232,30 @@ def main():
     if rank == 0:
         avg_ms = sum(kern_ms) / len(kern_ms)
         avg_clouds = sum(kern_clouds) / len(kern_clouds)
-        achieved = FLOP_DENSE_PER_CLOUD * avg_clouds / (avg_ms * 1e-3) / 1e12
+        achieved = flop_per_cloud * avg_clouds / (avg_ms * 1e-3) / 1e12
         traffic = None
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and not onet:
             traffic = json.load(open(tf)).get("optimize_kernel_hbm_bytes_per_launch")
         res = {
-            "metric": "restored clouds/sec (1024-pt ModelNet40, ConvONet-Opt 500 iters)",
+            "metric": "restored clouds/sec (1024-pt ModelNet40, %s 500 iters)" % ("ONet-Opt" if onet else "ConvONet-Opt"),
             "value": round(total * a.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ConvONet-Opt on ModelNet40-test-like .npz: %d clouds/GPU x 1024 pts, --iterations=500 "
+            "config": {"workload": "%s on ModelNet40-test-like .npz: %d clouds/GPU x 1024 pts, --iterations=500 "
                                    "(501 Adam steps), SOR on, batch_size 192; SOR+preprocess+encode+init+optimise+"
-                                   "normalise+gather" % a.clouds,
+                                   "normalise+gather" % ("ONet-Opt" if onet else "ConvONet-Opt", a.clouds),
                        "clouds_per_gpu": a.clouds, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
                        "parallelism": "shard%d+allgather" % world, "weights": "seeded random (seed 0)"},
-            "roofline": {"bound": "mfma", "kernel": "ifd::optimize_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "mfma", "kernel": "ifd::onet_optimize_kernel" if onet else "ifd::optimize_kernel",
+                         "achieved": round(achieved, 2),
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "launch_ms": round(avg_ms, 2), "clouds_per_launch": avg_clouds,
-                         "flop_per_cloud": FLOP_DENSE_PER_CLOUD},
+                         "flop_per_cloud": flop_per_cloud},
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(all_clouds)
+            res["cpu_baseline"] = cpu_baseline(all_clouds, onet=onet)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
