@@ -33,6 +33,12 @@ class IfdPrepParams(C.Structure):
                 ("init_sigma", C.c_float), ("seed", C.c_uint64), ("cloud_index_base", C.c_int64)]
 
 
+class IfdMeshParams(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("resolution0", C.c_int32), ("upsampling_steps", C.c_int32),
+                ("n_sample", C.c_int32), ("max_triangles", C.c_int32), ("padding", C.c_float), ("threshold", C.c_double),
+                ("seed", C.c_uint64), ("cloud_index_base", C.c_int64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/ifd.h declares (tests check this)
 SIGNATURES = {
     "ifd_abi_version": (C.c_int, []),
@@ -65,6 +71,9 @@ SIGNATURES = {
                                   C.c_void_p]),
     "ifd_onet_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ifd_onet_mesh_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(IfdMeshParams), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ifd_mc_table": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -97,6 +97,8 @@ struct ifd_ctx {
     float* d_onet_small = nullptr;
     OnetEncOffsets oe{};
     OnetDecOffsets od{};
+    void* ws_mesh = nullptr;       // ONet-Mesh scratch (MISE arrays, triangle soup)
+    size_t ws_mesh_bytes = 0;
     std::string err;
 };
 
@@ -353,6 +355,7 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->ws_enc) (void)hipFree(ctx->ws_enc);
     if (ctx->d_onet_img) (void)hipFree(ctx->d_onet_img);
     if (ctx->d_onet_small) (void)hipFree(ctx->d_onet_small);
+    if (ctx->ws_mesh) (void)hipFree(ctx->ws_mesh);
     delete ctx;
 }
 
@@ -555,6 +558,7 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e == hipSuccess) e = configure_onet_kernels();
+    if (e == hipSuccess) e = mc_upload_table();
     if (e != hipSuccess) {
         g_create_error = std::string("ifd_onet_create: ") + hipGetErrorString(e);
         ifd_destroy(ctx);
@@ -627,6 +631,94 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
         e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
                                  static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K, a, s);
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_onet_optimize", e);
+}
+
+int ifd_mc_table(int8_t* tri, uint8_t* ntri) {
+    if (!tri || !ntri) return IFD_ERR_ARG;
+    mc_host_table(reinterpret_cast<int8_t(*)[16]>(tri), ntri);
+    return IFD_OK;
+}
+
+int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_params* prm, float* points,
+                         int32_t* n_triangles, float* grid, float* triangles, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: not an ONet context");
+    if (!c || !prm || prm->struct_size != (int32_t)sizeof(ifd_mesh_params) || !points || !n_triangles || B < 1)
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: bad argument");
+    const int depth = prm->upsampling_steps, res0 = prm->resolution0;
+    if (depth < 0 || depth > 2 || res0 < 2 || (res0 << depth) > 128 || prm->n_sample < 1 || prm->max_triangles < 1 ||
+        !(prm->threshold > 0.0 && prm->threshold < 1.0))
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: resolution0 << upsampling_steps <= 128, steps <= 2, 0 < threshold < 1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MiseGrid g{};
+    g.res0 = res0; g.depth = depth; g.P = (res0 << depth) + 1; g.P3 = g.P * g.P * g.P;
+    g.cap = g.P3;                                   // every grid point can be queued once
+    g.pend_stride = ((size_t)g.P3 + 3) & ~(size_t)3;
+    g.sub_total = 0;
+    for (int l = 0; l < 4; ++l) {
+        g.sub_off[l] = g.sub_total;
+        if (l < depth) { const int nv = res0 << l; g.sub_total += nv * nv * nv; }
+    }
+    g.sub_total = (g.sub_total + 3) & ~3;
+    if (g.sub_total == 0) g.sub_total = 4;
+    g.threshold = std::log(prm->threshold) - std::log(1.0 - prm->threshold);        // generation.py:97
+    const float box = 1.0f + prm->padding;
+    const int NC = g.P + 1, ncube = NC * NC * NC, capT = prm->max_triangles;
+    // per-cloud scratch layout (bytes, every block 16-byte aligned)
+    auto al = [](size_t n) { return (n + 15) & ~(size_t)15; };
+    const size_t o_val = 0, o_known = o_val + al((size_t)g.P3 * 4), o_pend = o_known + al(g.P3), o_sub = o_pend + al(g.pend_stride),
+                 o_mix = o_sub + al(g.sub_total), o_list = o_mix + al(g.sub_total), o_cube = o_list + al((size_t)g.cap * 4),
+                 o_tris = o_cube + al((size_t)ncube * 4), o_area = o_tris + al((size_t)capT * 36), per = o_area + al((size_t)capT * 8);
+    const size_t fit = ((size_t)6 << 30) / per;                 // ~6 GB of scratch per pass
+    const int chunk = fit < 1 ? 1 : fit > (size_t)B ? B : (int)fit;
+    // layout: arrays are [chunk][stride] each (struct-of-arrays), plus count / ntri / ab folded separately
+    const size_t total = per * chunk + al((size_t)chunk * 4) * 2;
+    hipError_t e = ensure_buf(&ctx->ws_mesh, &ctx->ws_mesh_bytes, total);
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_mesh_sample workspace", e);
+    char* base = static_cast<char*>(ctx->ws_mesh);
+    auto blk = [&](size_t off_per_cloud) { return base + off_per_cloud * chunk; };
+    g.val = reinterpret_cast<float*>(blk(o_val));
+    g.known = reinterpret_cast<uint8_t*>(blk(o_known));
+    g.pend = reinterpret_cast<uint8_t*>(blk(o_pend));
+    g.sub = reinterpret_cast<uint8_t*>(blk(o_sub));
+    g.mix = reinterpret_cast<uint8_t*>(blk(o_mix));
+    g.list = reinterpret_cast<int*>(blk(o_list));
+    int* cube_offs = reinterpret_cast<int*>(blk(o_cube));
+    float* tris = reinterpret_cast<float*>(blk(o_tris));
+    double* area = reinterpret_cast<double*>(blk(o_area));
+    g.count = reinterpret_cast<int*>(base + per * chunk);
+    int* ntri = reinterpret_cast<int*>(base + per * chunk + al((size_t)chunk * 4));
+    std::vector<int> counts(chunk);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = B - b0 < chunk ? B - b0 : chunk;
+        float* ab = nullptr;
+        e = onet_fold(ctx, c + (size_t)b0 * ONET_C, nb, s, &ab);
+        if (e == hipSuccess) e = launch_mise_init(g, nb, s);
+        if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample init", e);
+        int max_count = (res0 + 1) * (res0 + 1) * (res0 + 1);
+        for (int round = 0; round < 64 && max_count > 0; ++round) {
+            e = launch_onet_grid_eval(ctx->d_onet_img, ctx->d_onet_small, ab, g, nb, max_count, box, s);
+            if (e == hipSuccess) e = launch_mise_update(g, nb, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), g.count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample round", e);
+            max_count = 0;
+            for (int b = 0; b < nb; ++b) max_count = counts[b] > max_count ? counts[b] : max_count;
+            if (max_count > g.cap) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample: point queue overflow");
+        }
+        e = launch_mise_fill(g, nb, s);
+        if (e == hipSuccess && grid)
+            e = hipMemcpyAsync(grid + (size_t)b0 * g.P3, g.val, (size_t)nb * g.P3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = launch_marching_cubes(g.val, nb, g.P, g.threshold, box, cube_offs, ntri, capT, tris, area, s);
+        if (e == hipSuccess)
+            e = launch_sample_surface(tris, area, ntri, nb, capT, prm->n_sample, prm->seed, (int)(prm->cloud_index_base + b0),
+                                      points + (size_t)b0 * prm->n_sample * 3, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(n_triangles + b0, ntri, (size_t)nb * sizeof(int), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess && triangles)
+            e = hipMemcpyAsync(triangles + (size_t)b0 * capT * 9, tris, (size_t)nb * capT * 9 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample", e);
+    }
+    return IFD_OK;
 }
 
 }  // extern "C"

@@ -79,4 +79,31 @@ hipError_t launch_onet_optimize(const float* img, const float* small, const floa
                                 float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
                                 unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s);
 
+// ---- ONet-Mesh (mesh.hip) --------------------------------------------------------------------------------
+// MISE state of a batch of clouds as dense arrays (per-cloud strides: P3 for val / known, pend_stride for pend,
+// sub_total for sub / mix, cap for list)
+struct MiseGrid {
+    int res0, depth, P, P3, cap, sub_total, sub_off[4];
+    size_t pend_stride;
+    double threshold;
+    float* val;          // [B][P3]   decoder logits at the grid points
+    uint8_t* known;      // [B][P3]
+    uint8_t* pend;       // [B][pend_stride]  queued for evaluation (byte flags)
+    uint8_t* sub;        // [B][sub_total]    voxel of level l subdivided (levels concatenated)
+    uint8_t* mix;        // [B][sub_total]    scratch of one update round
+    int* list;           // [B][cap]  grid-point indices to evaluate this round
+    int* count;          // [B]
+};
+hipError_t launch_mise_init(const MiseGrid& g, int B, hipStream_t s);
+hipError_t launch_mise_update(const MiseGrid& g, int B, hipStream_t s);
+hipError_t launch_mise_fill(const MiseGrid& g, int B, hipStream_t s);
+hipError_t launch_onet_grid_eval(const float* img, const float* small, const float* ab, const MiseGrid& g, int B,
+                                 int max_count, float box, hipStream_t s);
+hipError_t mc_upload_table();
+void mc_host_table(int8_t (*tri)[16], uint8_t* ntri);
+hipError_t launch_marching_cubes(const float* val, int B, int P, double iso, float box, int* cube_offs, int* ntri_total,
+                                 int cap, float* tris, double* area, hipStream_t s);
+hipError_t launch_sample_surface(const float* tris, const double* cum_area, const int* ntri_total, int B, int cap, int n,
+                                 uint64_t seed, int cloud_base, float* out, hipStream_t s);
+
 }  // namespace ifd

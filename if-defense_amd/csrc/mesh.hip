@@ -1,0 +1,409 @@
+// ONet-Mesh path (ONet/remesh_defense.py; BASELINE config #4): occupancy grid by
+// multi-resolution iso-surface extraction -> marching cubes -> area-weighted surface sampling, all on the GPU.
+//
+//   generate_from_latent (im2mesh/onet/generation.py:88-135) evaluates the decoder on a 33^3 grid and refines it twice
+//   around the surface (MISE, im2mesh/utils/libmise/mise.pyx) up to 129^3, extracts the iso-surface of the padded
+//   grid (extract_mesh :155-178, libmcubes) and remesh_defense.py:150-170 draws 1024 area-weighted surface samples.
+//
+// MISE as dense arrays instead of an octree with a hash map: per cloud val[P^3] / known[P^3] (P = R + 1 grid points
+// per axis) and one "subdivided" flag array per level.  A leaf voxel is subdivided when the known points of its
+// CLOSED cube lie on both sides of the threshold (mise.pyx:181-215: every known point marks the <= 8 leaf voxels that
+// touch it - including big unsubdivided neighbours, which is why activation can cascade over several rounds), which
+// adds the 27 points of the half-size lattice (:217-262).  Rounds repeat until no point is pending, like the
+// query / update loop of generation.py:112-127.  The values come from the MFMA decoder of onet.hip; comparisons with the
+// threshold are done in double like the reference (float32 logits widened to float64, generation.py:124).
+#include <cstring>
+
+#include "ifd_device.h"
+#include "ifd_internal.h"
+
+namespace ifd {
+
+// ---------------------------------------------------------------------------------------------
+// MISE bookkeeping
+// ---------------------------------------------------------------------------------------------
+__global__ void mise_init_kernel(MiseGrid g) {
+    // all lattice points of the coarsest level are pending (mise.pyx:76-86)
+    const int cloud = blockIdx.y;
+    const int n0 = g.res0 + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0 * n0 * n0) return;
+    const int s = 1 << g.depth;
+    const int x = (i / (n0 * n0)) * s, y = ((i / n0) % n0) * s, z = (i % n0) * s;
+    const int idx = (x * g.P + y) * g.P + z;
+    g.pend[(size_t)cloud * g.pend_stride + idx] = 1;
+    g.list[(size_t)cloud * g.cap + i] = idx;
+    if (i == 0) g.count[cloud] = n0 * n0 * n0;
+}
+
+// mixed[level][voxel] = leaf && known points of the closed cube on both sides of the threshold
+__global__ void mise_mark_kernel(MiseGrid g, int level) {
+    const int cloud = blockIdx.y;
+    const int nv = g.res0 << level;                                 // voxels per axis at this level
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv * nv * nv) return;
+    const int vx = v / (nv * nv), vy = (v / nv) % nv, vz = v % nv;
+    uint8_t* mix = g.mix + (size_t)cloud * g.sub_total + g.sub_off[level];
+    const uint8_t* sub = g.sub + (size_t)cloud * g.sub_total;
+    bool leaf = sub[g.sub_off[level] + v] == 0;
+    if (leaf && level > 0) {
+        const int np = nv >> 1;
+        leaf = sub[g.sub_off[level - 1] + ((vx >> 1) * np + (vy >> 1)) * np + (vz >> 1)] != 0;      // the voxel exists
+    }
+    bool pos = false, neg = false;
+    if (leaf) {
+        const int s = 1 << (g.depth - level);
+        const float* val = g.val + (size_t)cloud * g.P3;
+        const uint8_t* known = g.known + (size_t)cloud * g.P3;
+        for (int a = 0; a <= s; ++a)
+            for (int b = 0; b <= s; ++b)
+                for (int c = 0; c <= s; ++c) {
+                    const int idx = ((vx * s + a) * g.P + vy * s + b) * g.P + vz * s + c;
+                    if (known[idx]) {
+                        const double f = (double)val[idx];
+                        pos |= f >= g.threshold;
+                        neg |= f <= g.threshold;
+                    }
+                }
+    }
+    mix[v] = (pos && neg) ? 1 : 0;
+}
+
+// subdivide the marked voxels: flag them, queue the not-yet-known points of the half-size lattice
+__global__ void mise_apply_kernel(MiseGrid g, int level) {
+    const int cloud = blockIdx.y;
+    const int nv = g.res0 << level;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv * nv * nv) return;
+    if (!g.mix[(size_t)cloud * g.sub_total + g.sub_off[level] + v]) return;
+    g.sub[(size_t)cloud * g.sub_total + g.sub_off[level] + v] = 1;
+    const int vx = v / (nv * nv), vy = (v / nv) % nv, vz = v % nv;
+    const int s = 1 << (g.depth - level), h = s >> 1;
+    const uint8_t* known = g.known + (size_t)cloud * g.P3;
+    unsigned int* pend = reinterpret_cast<unsigned int*>(g.pend + (size_t)cloud * g.pend_stride);   // byte flags, word atomics
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            for (int c = 0; c < 3; ++c) {
+                const int idx = ((vx * s + a * h) * g.P + vy * s + b * h) * g.P + vz * s + c * h;
+                if (known[idx]) continue;
+                const unsigned int bit = 1u << (8 * (idx & 3));
+                const unsigned int old = atomicOr(pend + (idx >> 2), bit);
+                if (!(old & bit)) {
+                    const int at = atomicAdd(g.count + cloud, 1);
+                    if (at < g.cap) g.list[(size_t)cloud * g.cap + at] = idx;
+                }
+            }
+}
+
+// to_dense (mise.pyx:130-166): unknown entries take the value of their predecessor along x, then y, then z
+__global__ void mise_fill_kernel(MiseGrid g, int axis) {
+    const int cloud = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.P * g.P) return;
+    const int u = t / g.P, w = t % g.P;
+    float* val = g.val + (size_t)cloud * g.P3;
+    uint8_t* known = g.known + (size_t)cloud * g.P3;
+    const int stride = axis == 0 ? g.P * g.P : axis == 1 ? g.P : 1;
+    const int base = axis == 0 ? u * g.P + w : axis == 1 ? u * g.P * g.P + w : (u * g.P + w) * g.P;
+    for (int i = 1; i < g.P; ++i) {
+        const int idx = base + i * stride;
+        if (!known[idx] && known[idx - stride]) { val[idx] = val[idx - stride]; known[idx] = 1; }
+    }
+}
+
+hipError_t launch_mise_init(const MiseGrid& g, int B, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(g.known, 0, (size_t)B * g.P3, s);
+    if (e == hipSuccess) e = hipMemsetAsync(g.pend, 0, (size_t)B * g.pend_stride, s);
+    if (e == hipSuccess) e = hipMemsetAsync(g.sub, 0, (size_t)B * g.sub_total, s);
+    if (e != hipSuccess) return e;
+    const int n0 = (g.res0 + 1) * (g.res0 + 1) * (g.res0 + 1);
+    hipLaunchKernelGGL(mise_init_kernel, dim3((n0 + 255) / 256, B), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_mise_update(const MiseGrid& g, int B, hipStream_t s) {
+    // the evaluated points are known now; decisions of this round use the state at its start (mise.pyx:196-215:
+    // marks first, then subdivision of the voxels that existed), so: reset the queue, mark every level, then apply
+    hipError_t e = hipMemsetAsync(g.count, 0, (size_t)B * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    for (int l = 0; l < g.depth; ++l) {
+        const int nv = g.res0 << l, n = nv * nv * nv;
+        hipLaunchKernelGGL(mise_mark_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, g, l);
+    }
+    for (int l = 0; l < g.depth; ++l) {
+        const int nv = g.res0 << l, n = nv * nv * nv;
+        hipLaunchKernelGGL(mise_apply_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, g, l);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mise_fill(const MiseGrid& g, int B, hipStream_t s) {
+    for (int axis = 0; axis < 3; ++axis)
+        hipLaunchKernelGGL(mise_fill_kernel, dim3((g.P * g.P + 255) / 256, B), dim3(256), 0, s, g, axis);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// marching cubes on the padded grid (generation.py:155-178; libmcubes/marchingcubes.h:23-193)
+//
+// Corner / edge numbering and the inside test (value <= isovalue) are the reference's (= Bourke's): corners 0..3 =
+// (0,0,0) (1,0,0) (1,1,0) (0,1,0), 4..7 the same at z + 1; edges 0-3 bottom ring, 4-7 top ring, 8-11 verticals.
+// Vertices are the linear iso-crossings of the grid edges, identical to the reference's.  The polygonisation table is
+// NOT the classic 256 x 16 table: it is generated at start-up (mc_build_table, host) by tracing, for every sign
+// configuration, the closed loops the iso-surface cuts out of the cube faces and fanning each loop - a
+// crack-free triangulation of the same vertex loops (ambiguous faces: the two inside corners are connected).
+// ---------------------------------------------------------------------------------------------
+struct McTable {
+    int8_t tri[256][16];          // up to 5 triangles as edge triples, -1 terminated
+    uint8_t ntri[256];
+};
+__constant__ McTable c_mc;
+
+static const int kEdgeCorner[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+
+// Build the table on the host.  A face is a 4-cycle of corners; an inside/outside transition along a face edge is
+// an iso-crossing of that cube edge.  On every face the crossings are paired into segments (2 crossings: one segment;
+// 4 crossings - the ambiguous face - two segments that each cut off one OUTSIDE corner, i.e. the inside corners stay
+// connected).  Two faces share every cube edge and traverse it in opposite directions, so directed segments
+// (from the crossing that enters the inside set to the one that leaves it) chain head to tail into closed loops;
+// each loop is fanned from its first vertex.
+static void mc_build_table(McTable& T) {
+    // faces as corner 4-cycles, counter-clockwise seen from OUTSIDE the cube
+    static const int F[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {1, 2, 6, 5}, {3, 0, 4, 7}};
+    auto edge_of = [](int a, int b) {
+        for (int e = 0; e < 12; ++e)
+            if ((kEdgeCorner[e][0] == a && kEdgeCorner[e][1] == b) || (kEdgeCorner[e][0] == b && kEdgeCorner[e][1] == a)) return e;
+        return -1;
+    };
+    for (int cfg = 0; cfg < 256; ++cfg) {
+        int nxt[12];
+        for (int e = 0; e < 12; ++e) nxt[e] = -1;
+        for (int f = 0; f < 6; ++f) {
+            int in[4];
+            for (int i = 0; i < 4; ++i) in[i] = (cfg >> F[f][i]) & 1;
+            int nin = in[0] + in[1] + in[2] + in[3];
+            if (nin == 0 || nin == 4) continue;
+            // crossings on face edge i (corner i -> corner i+1)
+            for (int i = 0; i < 4; ++i) {
+                const int j = (i + 1) & 3;
+                if (in[i] && !in[j]) {
+                    // leaving the inside at edge i: follow the outside run to where the inside is entered again
+                    int k = j;
+                    while (!in[(k + 1) & 3]) k = (k + 1) & 3;
+                    // entering at face edge k (corner k -> k+1)
+                    const int e_out = edge_of(F[f][i], F[f][j]), e_in = edge_of(F[f][k], F[f][(k + 1) & 3]);
+                    nxt[e_in] = e_out;
+                }
+            }
+        }
+        int n = 0;
+        bool used[12] = {false};
+        for (int e0 = 0; e0 < 12; ++e0) {
+            if (nxt[e0] < 0 || used[e0]) continue;
+            int loop[12], len = 0;
+            for (int e = e0; !used[e]; e = nxt[e]) { used[e] = true; loop[len++] = e; }
+            for (int i = 1; i + 1 < len && n + 3 <= 15; ++i) {
+                T.tri[cfg][n++] = (int8_t)loop[0];
+                T.tri[cfg][n++] = (int8_t)loop[i];
+                T.tri[cfg][n++] = (int8_t)loop[i + 1];
+            }
+        }
+        T.ntri[cfg] = (uint8_t)(n / 3);
+        for (; n < 16; ++n) T.tri[cfg][n] = -1;
+    }
+}
+
+hipError_t mc_upload_table() {
+    static McTable T;
+    static bool built = false;
+    if (!built) { mc_build_table(T); built = true; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_mc), &T, sizeof(McTable));
+}
+void mc_host_table(int8_t (*tri)[16], uint8_t* ntri) {
+    McTable T;
+    mc_build_table(T);
+    std::memcpy(tri, T.tri, sizeof(T.tri));
+    std::memcpy(ntri, T.ntri, sizeof(T.ntri));
+}
+
+__device__ __forceinline__ float padded_value(const float* __restrict__ val, int P, int x, int y, int z) {
+    // np.pad(occ_hat, 1, 'constant', constant_values=-1e6) (generation.py:168-169): padded index -> grid index - 1
+    if (x < 1 || y < 1 || z < 1 || x > P || y > P || z > P) return -1e6f;
+    return val[((x - 1) * P + (y - 1)) * P + (z - 1)];
+}
+
+__device__ __forceinline__ int cube_config(const float* __restrict__ val, int P, int x, int y, int z, double iso, double (&f)[8]) {
+    const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    int cfg = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f[m] = (double)padded_value(val, P, x + ox[m], y + oy[m], z + oz[m]);
+        if (f[m] <= iso) cfg |= 1 << m;                                // marchingcubes.h:62-64
+    }
+    return cfg;
+}
+
+// pass 1: triangles per cube (padded grid has P + 2 points -> P + 1 cubes per axis)
+__global__ void mc_count_kernel(const float* __restrict__ val, int P, double iso, int* __restrict__ ntri) {
+    const int cloud = blockIdx.y, NC = P + 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC * NC * NC) return;
+    double f[8];
+    const int cfg = cube_config(val + (size_t)cloud * P * P * P, P, c / (NC * NC), (c / NC) % NC, c % NC, iso, f);
+    ntri[(size_t)cloud * NC * NC * NC + c] = c_mc.ntri[cfg];
+}
+
+// exclusive scan of the per-cube counts, one block per cloud (deterministic triangle order = cube order)
+__global__ __launch_bounds__(1024) void mc_scan_kernel(int* __restrict__ ntri, int n, int* __restrict__ total) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    int* a = ntri + (size_t)blockIdx.x * n;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024 * 8) {
+        int v[8], sum = 0;
+        const int i0 = base + threadIdx.x * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = i0 + j < n ? a[i0 + j] : 0; sum += v[j]; }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                           // Hillis-Steele inclusive scan of the partials
+            const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int run = carry + part[threadIdx.x] - sum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { if (i0 + j < n) a[i0 + j] = run; run += v[j]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[blockIdx.x] = carry;
+}
+
+// pass 2: emit the triangles (vertex coordinates in the decoder's frame, generation.py:171-176) and their areas
+__global__ void mc_emit_kernel(const float* __restrict__ val, int P, double iso, float box, const int* __restrict__ offs,
+                               int cap, float* __restrict__ tris, double* __restrict__ area) {
+    const int cloud = blockIdx.y, NC = P + 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC * NC * NC) return;
+    const int x = c / (NC * NC), y = (c / NC) % NC, z = c % NC;
+    double f[8];
+    const int cfg = cube_config(val + (size_t)cloud * P * P * P, P, x, y, z, iso, f);
+    const int n = c_mc.ntri[cfg];
+    if (n == 0) return;
+    const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    const int ec[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    int at = offs[(size_t)cloud * NC * NC * NC + c];
+    for (int t = 0; t < n && at < cap; ++t, ++at) {
+        double p[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = c_mc.tri[cfg][3 * t + k], a = ec[e][0], b = ec[e][1];
+            // mc_isovalue_interpolation (marchingcubes.cpp:290-297)
+            const double w = f[b] == f[a] ? 0.5 : (iso - f[a]) / (f[b] - f[a]);
+            const double gx = x + ox[a] + (ox[b] - ox[a]) * w, gy = y + oy[a] + (oy[b] - oy[a]) * w,
+                         gz = z + oz[a] + (oz[b] - oz[a]) * w;
+            // libmcubes' +0.5 shift undone, padding undone, normalised to the bounding box (generation.py:171-176)
+            p[k][0] = (double)box * ((gx - 1.0) / (double)(P - 1) - 0.5);
+            p[k][1] = (double)box * ((gy - 1.0) / (double)(P - 1) - 0.5);
+            p[k][2] = (double)box * ((gz - 1.0) / (double)(P - 1) - 0.5);
+        }
+        float* o = tris + ((size_t)cloud * cap + at) * 9;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o[3 * k] = (float)p[k][0]; o[3 * k + 1] = (float)p[k][1]; o[3 * k + 2] = (float)p[k][2]; }
+        const double ux = p[1][0] - p[0][0], uy = p[1][1] - p[0][1], uz = p[1][2] - p[0][2];
+        const double vx = p[2][0] - p[0][0], vy = p[2][1] - p[0][1], vz = p[2][2] - p[0][2];
+        const double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+        area[(size_t)cloud * cap + at] = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
+    }
+}
+
+// inclusive scan of the triangle areas (double), one block per cloud
+__global__ __launch_bounds__(1024) void area_scan_kernel(double* __restrict__ area, const int* __restrict__ ntri_total, int cap) {
+    __shared__ double part[1024];
+    __shared__ double carry;
+    const int n = min(ntri_total[blockIdx.x], cap);
+    double* a = area + (size_t)blockIdx.x * cap;
+    if (threadIdx.x == 0) carry = 0.0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024 * 8) {
+        double v[8], sum = 0.0;
+        const int i0 = base + threadIdx.x * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = i0 + j < n ? a[i0 + j] : 0.0; sum += v[j]; }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const double t = threadIdx.x >= o ? part[threadIdx.x - o] : 0.0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        double run = carry + part[threadIdx.x] - sum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { run += v[j]; if (i0 + j < n) a[i0 + j] = run; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+// Philox-4x32-10 (same generator as prep.hip), keyed by (seed, global cloud index), counter = sample index
+__device__ __forceinline__ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// trimesh.sample.sample_surface (remesh_defense.py:155-156): pick a face with probability ~ area, then a uniform
+// point of it (two uniforms, reflected into the triangle).  out [B][n][3]; empty meshes leave their rows untouched.
+__global__ void sample_surface_kernel(const float* __restrict__ tris, const double* __restrict__ cum_area,
+                                      const int* __restrict__ ntri_total, int cap, int n, uint32_t seed_lo, uint32_t seed_hi,
+                                      int cloud_base, float* __restrict__ out) {
+    const int cloud = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nt = min(ntri_total[cloud], cap);
+    if (i >= n || nt == 0) return;
+    uint32_t r[4];
+    philox4(seed_lo, seed_hi, (uint32_t)i, 0x5a3fu, (uint32_t)(cloud_base + cloud), 0u, r);
+    const double* ca = cum_area + (size_t)cloud * cap;
+    const double target = ((double)r[0] + (double)r[1] * 4294967296.0) * (1.0 / 18446744073709551616.0) * ca[nt - 1];
+    int lo = 0, hi = nt - 1;                                           // first index with cum_area > target
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ca[mid] > target) hi = mid; else lo = mid + 1;
+    }
+    float u = (float)r[2] * (1.0f / 4294967296.0f), v = (float)r[3] * (1.0f / 4294967296.0f);
+    if (u + v > 1.f) { u = 1.f - u; v = 1.f - v; }
+    const float* t = tris + ((size_t)cloud * cap + lo) * 9;
+    float* o = out + ((size_t)cloud * n + i) * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[a] = t[a] + u * (t[3 + a] - t[a]) + v * (t[6 + a] - t[a]);
+}
+
+hipError_t launch_marching_cubes(const float* val, int B, int P, double iso, float box, int* cube_offs, int* ntri_total,
+                                 int cap, float* tris, double* area, hipStream_t s) {
+    const int NC = P + 1, n = NC * NC * NC;
+    hipLaunchKernelGGL(mc_count_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, val, P, iso, cube_offs);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(B), dim3(1024), 0, s, cube_offs, n, ntri_total);
+    hipLaunchKernelGGL(mc_emit_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, val, P, iso, box, cube_offs, cap, tris, area);
+    hipLaunchKernelGGL(area_scan_kernel, dim3(B), dim3(1024), 0, s, area, ntri_total, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_surface(const float* tris, const double* cum_area, const int* ntri_total, int B, int cap, int n,
+                                 uint64_t seed, int cloud_base, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sample_surface_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, tris, cum_area, ntri_total, cap, n,
+                       (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), cloud_base, out);
+    return hipGetLastError();
+}
+
+}  // namespace ifd

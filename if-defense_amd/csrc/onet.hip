@@ -426,6 +426,49 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_decode_kernel(const float
     }
 }
 
+// Occupancy at the queued grid points of the MISE rounds (mesh.hip; generation.py:112-127 eval_points): block
+// (segment, cloud) evaluates `seg` entries of the cloud's point list, 128 per pass, forward only.
+constexpr int GRID_SEG = 2048;
+__global__ __launch_bounds__(OPT_THREADS, 2) void onet_grid_eval_kernel(const float* __restrict__ img, const float* __restrict__ small,
+                                                                         const float* __restrict__ ab, MiseGrid g, float box) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int cloud = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(g.count[cloud], g.cap), first = blockIdx.x * GRID_SEG;
+    if (first >= n) return;                                                    // block-uniform
+    onet_prologue(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);
+    const int* list = g.list + (size_t)cloud * g.cap;
+    const float inv_r = (float)(g.P - 1);
+    const int last = min(n, first + GRID_SEG);
+    for (int base = first; base < last; base += 128) {
+        const int i = base + wave * 16 + (lane & 15);
+        const int idx = list[min(i, n - 1)];
+        const int x = idx / (g.P * g.P), y = (idx / g.P) % g.P, z = idx % g.P;
+        // pointsf / resolution, box_size * (pointsf - 0.5) in float32 (generation.py:117-121)
+        const float px = ((float)x / inv_r - 0.5f) * box, py = ((float)y / inv_r - 0.5f) * box, pz = ((float)z / inv_r - 0.5f) * box;
+        float logit, bce, dx[3];
+        onet_pass<OMODE_SUM, false>(img, smem, wave, lane, px, py, pz, 0.f, 1.f, logit, bce, dx);
+        if (lane < 16 && i < last) {
+            g.val[(size_t)cloud * g.P3 + idx] = logit;
+            g.known[(size_t)cloud * g.P3 + idx] = 1;
+        }
+    }
+}
+
+hipError_t launch_onet_grid_eval(const float* img, const float* small, const float* ab, const MiseGrid& g, int B, int max_count,
+                                 float box, hipStream_t s) {
+    if (max_count <= 0) return hipSuccess;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(onet_grid_eval_kernel, dim3((max_count + GRID_SEG - 1) / GRID_SEG, B), dim3(OPT_THREADS), ONET_DEC_LDS, s, img,
+                       small, ab, g, box);
+    return hipGetLastError();
+}
+
 // The ONet-Opt optimiser (ONet/opt_defense.py:182-239): same skeleton as optimize_kernel, decoder passes instead
 // of plane tiles.  The kNN phase is ~1 % of a step here, so all waves simply run it first.
 __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(

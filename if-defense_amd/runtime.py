@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import IfdConfig, IfdOptParams, IfdPrepParams
+from ._lib import IfdConfig, IfdMeshParams, IfdOptParams, IfdPrepParams
 
 PLANE_ORDER = ("xz", "xy", "yz")
 
@@ -292,6 +292,32 @@ class OnetRestorer(Restorer):
             self._check(self.lib.ifd_onet_encode(self.ctx, sel.data_ptr(), self._ptr(tpc), B, T, c.data_ptr(),
                                                  self._stream()))
         return c
+
+    def mesh_sample(self, c: torch.Tensor, n_sample: int = 1024, resolution0: int = 32, upsampling_steps: int = 2,
+                    padding: float = 0.1, seed: int = 0, cloud_index_base: int = 0, max_triangles: int = 400000,
+                    want_grid: bool = False, want_triangles: bool = False, threshold: Optional[float] = None):
+        """reconstruct_mesh + trimesh.sample.sample_surface (ONet/remesh_defense.py:128-157) for a batch of latent codes:
+        c [B,512] -> dict(points [B,n_sample,3] (not normalised), n_triangles [B] int32, optionally grid [B,P,P,P] and
+        triangles [B,max_triangles,9])."""
+        c = self._cond(c)
+        B = c.shape[0]
+        P = (resolution0 << upsampling_steps) + 1
+        pts = torch.zeros(B, n_sample, 3, device=self.device, dtype=torch.float32)
+        ntri = torch.zeros(B, device=self.device, dtype=torch.int32)
+        grid = torch.empty(B, P, P, P, device=self.device, dtype=torch.float32) if want_grid else None
+        tris = torch.zeros(B, max_triangles, 9, device=self.device, dtype=torch.float32) if want_triangles else None
+        prm = IfdMeshParams(C.sizeof(IfdMeshParams), int(resolution0), int(upsampling_steps), int(n_sample), int(max_triangles),
+                            float(padding), float(self.threshold if threshold is None else threshold), int(seed),
+                            int(cloud_index_base))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_onet_mesh_sample(self.ctx, c.data_ptr(), B, C.byref(prm), pts.data_ptr(), ntri.data_ptr(),
+                                                      self._ptr(grid), self._ptr(tris), self._stream()))
+        out = {"points": pts, "n_triangles": ntri}
+        if want_grid:
+            out["grid"] = grid
+        if want_triangles:
+            out["triangles"] = tris
+        return out
 
     def encode_points(self, *a, **k):
         raise IfdError("encode_points / unet belong to the ConvONet model")

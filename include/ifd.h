@@ -234,6 +234,39 @@ int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, 
 int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, const ifd_opt_params* prm,
                       const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ONet-Mesh path (ONet/remesh_defense.py; BASELINE config #4), on an ONet context.
+ *
+ * reconstruct_mesh + resample_points (remesh_defense.py:128-170): generator.generate_from_latent(z, c)
+ * (im2mesh/onet/generation.py:88-178: MISE occupancy grid, resolution0 32 and 2 upsampling steps -> 129^3, marching
+ * cubes on the -1e6-padded grid) followed by trimesh.sample.sample_surface(mesh, n_sample).
+ *   c [B,512] -> points [B,n_sample,3] (NOT yet normalised: call ifd_normalize_unit_sphere, remesh_defense.py:262),
+ *   n_triangles [B] (device int32; 0 = empty mesh: the cloud's rows of `points` are left untouched and the caller
+ *   applies the reference's fallback, remesh_defense.py:160-170).
+ * Optional outputs for inspection / tests: grid [B,P,P,P] float32 (P = resolution0 * 2^upsampling_steps + 1; MISE's
+ * to_dense()), triangles [B,max_triangles,9] float32 (three xyz vertices per triangle in the decoder's frame; the
+ * first n_triangles[b] rows are valid).  The surface samples use the counter-based generator of ifd_prepare, keyed by
+ * (seed, cloud_index_base + b, sample index) - the reference's are unseeded numpy draws.
+ * Synchronises the stream once per MISE round (the host reads the number of queued grid points). */
+typedef struct ifd_mesh_params {
+    int32_t struct_size;       /* sizeof(ifd_mesh_params) */
+    int32_t resolution0;       /* cfg generation.resolution_0 (32) */
+    int32_t upsampling_steps;  /* cfg generation.upsampling_steps (2); 0..2, resolution0 << steps <= 128 */
+    int32_t n_sample;          /* args.sample_npoint (1024) */
+    int32_t max_triangles;     /* capacity per cloud of the triangle buffer (e.g. 400000) */
+    float padding;             /* Generator3D padding (0.1): box_size = 1 + padding */
+    double threshold;          /* cfg test.threshold (0.2), as a probability; the iso-value is its logit */
+    uint64_t seed;
+    int64_t cloud_index_base;
+} ifd_mesh_params;
+
+int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_params* prm, float* points,
+                         int32_t* n_triangles, float* grid, float* triangles, void* stream);
+
+/* The marching-cubes polygonisation table this library generates at start-up (host memory: tri [256*16] edge
+ * triples terminated by -1, ntri [256]).  Corner / edge numbering as in libmcubes (marchingcubes.h:44-64). */
+int ifd_mc_table(int8_t* tri, uint8_t* ntri);
+
 #ifdef __cplusplus
 }
 #endif

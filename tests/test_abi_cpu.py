@@ -102,3 +102,51 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_marching_cubes_table_is_a_valid_polygonisation():
+    """The start-up generated table (ifd_mc_table): triangles only use edges the surface crosses, every crossed edge is
+    used, at most 5 triangles, and the segments left on each cube face are the same for both cubes sharing the face
+    (crack-free), whatever the configuration of the neighbour."""
+    import ctypes as C
+    import numpy as np
+    from ifdefense_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    tri = np.zeros((256, 16), np.int8)
+    ntri = np.zeros(256, np.uint8)
+    assert lib.ifd_mc_table(tri.ctypes.data_as(C.c_void_p), ntri.ctypes.data_as(C.c_void_p)) == 0
+    EC = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+    faces = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (3, 0, 4, 7)]
+    assert ntri.max() == 5 and ntri[0] == 0 and ntri[255] == 0
+
+    def face_segments(cfg, face):
+        fe = {frozenset((face[i], face[(i + 1) % 4])) for i in range(4)}
+        on_face = [e for e, (a, b) in enumerate(EC) if frozenset((a, b)) in fe]
+        segs = set()
+        for t in range(ntri[cfg]):
+            e3 = [int(x) for x in tri[cfg, 3 * t:3 * t + 3]]
+            for i in range(3):
+                a, b = e3[i], e3[(i + 1) % 3]
+                if a in on_face and b in on_face:
+                    s = frozenset((a, b))
+                    segs ^= {s}                      # interior fan diagonals lying in a face would cancel in pairs
+        return segs
+
+    for cfg in range(256):
+        crossed = {e for e, (a, b) in enumerate(EC) if ((cfg >> a) & 1) != ((cfg >> b) & 1)}
+        used = {int(x) for x in tri[cfg, :3 * ntri[cfg]]}
+        assert used == crossed, cfg
+        assert (tri[cfg, 3 * ntri[cfg]:] == -1).all()
+        # each face: the surface leaves exactly the segments the face rule prescribes (depends on the face's 4 signs only)
+        for face in faces:
+            signs = tuple((cfg >> c) & 1 for c in face)
+            n_cross = sum(signs[i] != signs[(i + 1) % 4] for i in range(4))
+            assert len(face_segments(cfg, face)) == n_cross // 2, (cfg, face)
+    # crack-freeness: the segments on a face are a function of that face's corner signs alone
+    seen = {}
+    for cfg in range(256):
+        for face in faces:
+            signs = tuple((cfg >> c) & 1 for c in face)
+            key = (face, signs)
+            segs = face_segments(cfg, face)
+            assert seen.setdefault(key, segs) == segs, (cfg, face)

@@ -604,3 +604,99 @@ def test_onet_cli_end_to_end(tmp_path):
     assert sorted(z.files) == ["test_label", "test_pc"]
     assert z["test_pc"].shape == (4, 1024, 3) and z["test_pc"].dtype == np.float32 and z["test_label"].dtype == np.uint8
     np.testing.assert_allclose(np.linalg.norm(z["test_pc"], axis=-1).max(axis=1), 1.0, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# ONet-Mesh path (BASELINE config #4): MISE occupancy grid, marching cubes, surface sampling - against the reference's
+# own native libraries (oracle/_ref, built by oracle/build_ref.py from the sources under /root/reference)
+# ------------------------------------------------------------------------------------------------
+def _ref_libs():
+    import os, sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    if not os.path.isdir(d) or not any(f.startswith("mise") for f in os.listdir(d)):
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py needs /root/reference)")
+    sys.path.insert(0, d)
+    import mcubes, mise
+    return mise, mcubes
+
+
+def _cutting_threshold(onet, c):
+    """The random-weight occupancy field never crosses logit(0.2) (the box would come out "full"): use the median
+    occupancy over the box as the probability threshold so that the iso-surface cuts through the volume."""
+    g = torch.Generator().manual_seed(9)
+    p = (torch.rand(c.shape[0], 4096, 3, generator=g) - 0.5) * 1.1
+    med = float(onet.decode(p, c).median())
+    return float(1.0 / (1.0 + np.exp(-med)))
+
+
+def _reference_grid(onet, mise, c_row, res0, steps, threshold, padding=0.1):
+    """generate_from_latent's MISE loop (generation.py:97-129) around the reference's MISE class, with the occupancy
+    values coming from the HIP decoder (the point set evaluated each round is what is under test)."""
+    thr = np.log(threshold) - np.log(1. - threshold)
+    m = mise.MISE(res0, steps, thr)
+    pts = m.query()
+    rounds = 0
+    while pts.shape[0] != 0:
+        pf = torch.from_numpy(pts.astype(np.float32))                    # torch.FloatTensor(points)
+        pf = pf / m.resolution
+        pf = (1 + padding) * (pf - 0.5)
+        v = onet.decode(pf[None], c_row[None])[0].cpu().numpy().astype(np.float64)
+        m.update(pts, v)
+        pts = m.query()
+        rounds += 1
+    return m.to_dense(), thr, rounds
+
+
+@pytest.mark.parametrize("res0,steps", [(8, 2), (16, 1), (32, 2)])
+def test_onet_mesh_grid_and_surface_match_reference_libs(onet, og, res0, steps):
+    mise, mcubes = _ref_libs()
+    c = torch.from_numpy(og["c"][:2])
+    MESH_THRESHOLD = _cutting_threshold(onet, c)
+    out = onet.mesh_sample(c, n_sample=1024, resolution0=res0, upsampling_steps=steps, seed=3, want_grid=True,
+                           want_triangles=True, max_triangles=300000, threshold=MESH_THRESHOLD)
+    grid = out["grid"].cpu().numpy()
+    ntri = out["n_triangles"].cpu().numpy()
+    P = (res0 << steps) + 1
+    for b in range(2):
+        ref_grid, thr, rounds = _reference_grid(onet, mise, c[b], res0, steps, MESH_THRESHOLD)
+        assert ref_grid.shape == (P, P, P)
+        assert np.array_equal(grid[b].astype(np.float64), ref_grid), (b, np.abs(grid[b] - ref_grid).max())     # bit-exact
+        # marching cubes of the reference on the same grid (generation.py:166-176)
+        v, t = mcubes.marching_cubes(np.pad(ref_grid, 1, 'constant', constant_values=-1e6), thr)
+        v = 1.1 * ((v - 0.5 - 1) / (P - 1) - 0.5)
+        tris = out["triangles"][b, :ntri[b]].cpu().numpy().reshape(-1, 3, 3)
+        assert ntri[b] > 0 and len(t) > 0
+        # same vertices (the iso-crossings of the grid edges); triangles may fan the same loops differently
+        mine = np.unique(np.round(tris.reshape(-1, 3), 5), axis=0)
+        theirs = np.unique(np.round(v, 5), axis=0)
+        from scipy.spatial import cKDTree
+        d_mt, _ = cKDTree(theirs).query(mine)
+        d_tm, _ = cKDTree(mine).query(theirs)
+        assert abs(len(mine) - len(theirs)) <= 8 and d_mt.max() < 3e-5 and d_tm.max() < 3e-5, (mine.shape, theirs.shape)
+        def area(tr):
+            return 0.5 * np.linalg.norm(np.cross(tr[:, 1] - tr[:, 0], tr[:, 2] - tr[:, 0]), axis=1).sum()
+        a_mine, a_ref = area(tris), area(v[t.astype(np.int64)])
+        assert abs(a_mine - a_ref) / a_ref < 5e-3, (a_mine, a_ref)
+        # watertight: every undirected edge of the soup is shared by exactly two triangles
+        key = np.round(tris, 5)
+        e = np.concatenate([key[:, [0, 1]], key[:, [1, 2]], key[:, [2, 0]]]).reshape(-1, 6)
+        a_, b_ = e[:, :3], e[:, 3:]
+        swap = np.array([tuple(x) > tuple(y) for x, y in zip(a_, b_)])
+        e = np.where(swap[:, None], np.concatenate([b_, a_], 1), np.concatenate([a_, b_], 1))
+        # (on the box boundary the -1e6 padding collapses several crossings onto one grid point, which this
+        # coordinate-keyed count cannot tell apart: look at the edges strictly inside the box)
+        inner = (np.abs(e) < 0.55 - 1e-3).all(1)
+        _, cnt = np.unique(e[inner], axis=0, return_counts=True)
+        # (a grid corner within ~1e-4 of the iso-value pulls the crossings of its edges onto one point: a handful)
+        assert (cnt != 2).mean() < 5e-3 and (cnt % 2 == 0).all(), np.bincount(cnt)
+        # the samples lie on the surface: nearest mesh vertex within one voxel diagonal
+        from scipy.spatial import cKDTree
+        s = out["points"][b].cpu().numpy()
+        d, _ = cKDTree(theirs).query(s)
+        assert d.max() < 1.1 / (P - 1) * 1.8, d.max()
+        print("ONet-Mesh res0=%d steps=%d cloud %d: %d MISE rounds, %d triangles (reference %d), area %.4f vs %.4f" %
+              (res0, steps, b, rounds, ntri[b], len(t), a_mine, a_ref))
+    # sharding / seeding: same seed + global index -> same samples
+    again = onet.mesh_sample(c[1:], n_sample=1024, resolution0=res0, upsampling_steps=steps, seed=3, cloud_index_base=1,
+                             threshold=MESH_THRESHOLD)
+    assert torch.equal(again["points"][0], out["points"][1])
