@@ -98,6 +98,7 @@ struct ifd_ctx {
     OnetEncOffsets oe{};
     OnetDecOffsets od{};
     void* ws_mesh = nullptr;       // ONet-Mesh scratch (MISE arrays, triangle soup)
+    unsigned long long mesh_points = 0, mesh_rounds = 0;   // grid points evaluated / MISE rounds of the last mesh call
     size_t ws_mesh_bytes = 0;
     std::string err;
 };
@@ -475,6 +476,8 @@ int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
     unsigned long long tmp[IFD_N_COUNTERS] = {0};
     hipError_t e = hipMemcpy(tmp, ctx->d_counters, sizeof(tmp), hipMemcpyDeviceToHost);   // synchronises
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_get_counters", e);
+    tmp[8] = ctx->mesh_points;     // host-side tallies of the last ifd_onet_mesh_sample
+    tmp[9] = ctx->mesh_rounds;
     for (int i = 0; i < n; ++i) out_host[i] = i < IFD_N_COUNTERS ? tmp[i] : 0;
     return IFD_OK;
 }
@@ -689,6 +692,8 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
     g.count = reinterpret_cast<int*>(base + per * chunk);
     int* ntri = reinterpret_cast<int*>(base + per * chunk + al((size_t)chunk * 4));
     std::vector<int> counts(chunk);
+    ctx->mesh_points = 0;
+    ctx->mesh_rounds = 0;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = B - b0 < chunk ? B - b0 : chunk;
         float* ab = nullptr;
@@ -696,14 +701,16 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
         if (e == hipSuccess) e = launch_mise_init(g, nb, s);
         if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample init", e);
         int max_count = (res0 + 1) * (res0 + 1) * (res0 + 1);
+        ctx->mesh_points += (unsigned long long)max_count * nb;
         for (int round = 0; round < 64 && max_count > 0; ++round) {
+            ++ctx->mesh_rounds;
             e = launch_onet_grid_eval(ctx->d_onet_img, ctx->d_onet_small, ab, g, nb, max_count, box, s);
             if (e == hipSuccess) e = launch_mise_update(g, nb, s);
             if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), g.count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample round", e);
             max_count = 0;
-            for (int b = 0; b < nb; ++b) max_count = counts[b] > max_count ? counts[b] : max_count;
+            for (int b = 0; b < nb; ++b) { max_count = counts[b] > max_count ? counts[b] : max_count; ctx->mesh_points += counts[b]; }
             if (max_count > g.cap) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample: point queue overflow");
         }
         e = launch_mise_fill(g, nb, s);

@@ -66,15 +66,52 @@ def defend_point_cloud(r: Restorer, pc, args: DefenseArgs, cloud_index_base: int
     return out if return_device else out.cpu().numpy()
 
 
+def remesh_point_cloud(r, pc, args: "DefenseArgs", cloud_index_base: int = 0, return_device: bool = False,
+                       normalize: bool = True):
+    """ONet/remesh_defense.py:228-262 for an array of clouds: SOR -> preprocess (300-point subset) -> encode ->
+    reconstruct_mesh (MISE grid + marching cubes) -> 1024 area-weighted surface samples -> normalize_pc
+    (``normalize=False`` for the train split, which the reference leaves un-normalised, :208-211).
+
+    pc [N,K,3] -> [N,sample_npoint,3].  A cloud whose mesh comes out empty gets the reference's fallback
+    (remesh_defense.py:160-170): its (post-SOR) input points, zero-padded or randomly subsampled to sample_npoint.
+    """
+    x = torch.as_tensor(pc)[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
+    N, K = x.shape[:2]
+    n = int(args.sample_npoint)
+    out = torch.empty(N, n, 3, device=r.device, dtype=torch.float32)
+    for lo in range(0, N, int(args.chunk)):
+        hi = min(N, lo + int(args.chunk))
+        xb = x[lo:hi]
+        keep = r.sor(xb, args.sor_k, args.sor_alpha) if args.sor else None
+        prep = r.prepare(xb, keep, n_sel=args.input_npoint, n_opt=n, padding_scale=args.padding_scale,
+                         init_sigma=args.init_sigma, seed=args.seed, cloud_index_base=cloud_index_base + lo)
+        c = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        res = r.mesh_sample(c, n_sample=n, seed=args.seed, cloud_index_base=cloud_index_base + lo)
+        pts = res["points"]
+        empty = (res["n_triangles"] == 0).nonzero().flatten().tolist()
+        for b in empty:                                          # rare: reconstruction failed
+            ori = xb[b][keep[b].bool()] if keep is not None else xb[b]
+            fb = torch.zeros(n, 3, device=r.device)
+            if ori.shape[0] > n:
+                g = torch.Generator().manual_seed(int(args.seed) * 1000003 + cloud_index_base + lo + b)
+                ori = ori[torch.randperm(ori.shape[0], generator=g)[:n].to(r.device)]
+            fb[:ori.shape[0]] = ori
+            pts[b] = fb
+        out[lo:hi] = r.normalize_batch_pc(pts) if normalize else pts
+    return out if return_device else out.cpu().numpy()
+
+
 def get_save_name(path: str, model: str = "convonet") -> str:
     """opt_defense.py:242-252: <dir>/ConvONet-Opt/convonet_opt-<basename> (ONet/opt_defense.py: ONet-Opt/onet_opt-)."""
     sub = path.split('/')
-    folder = os.path.join(path[:path.rindex(sub[-1])], 'ONet-Opt' if model == "onet" else 'ConvONet-Opt')
+    folder_name, prefix = {"onet": ('ONet-Opt', 'onet_opt-'), "onet-mesh": ('ONet-Mesh', 'onet_remesh-')}.get(
+        model, ('ConvONet-Opt', 'convonet_opt-'))                 # ONet/remesh_defense.py:173-184
+    folder = os.path.join(path[:path.rindex(sub[-1])], folder_name)
     os.makedirs(folder, exist_ok=True)
-    return os.path.join(folder, ('onet_opt-' if model == "onet" else 'convonet_opt-') + sub[-1])
+    return os.path.join(folder, prefix + sub[-1])
 
 
-def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None) -> str:
+def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None, save_model=None) -> str:
     """opt_defense.py:317-344: test_pc / test_label (/ target_label) in, same keys out (float32 / uint8)."""
     npz = np.load(path)
     test_pc = npz['test_pc'][..., :3]
@@ -82,7 +119,7 @@ def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None)
     target_label = npz['target_label'] if 'target_label' in npz.files else None
     fn = defend or (lambda a: defend_point_cloud(r, a, args))
     out = fn(test_pc)
-    save_path = get_save_name(path, getattr(r, 'model_name', 'convonet'))
+    save_path = get_save_name(path, save_model or getattr(r, 'model_name', 'convonet'))
     kw = dict(test_pc=out.astype(np.float32), test_label=test_label.astype(np.uint8))
     if target_label is not None:
         kw['target_label'] = target_label.astype(np.uint8)
@@ -91,13 +128,13 @@ def defend_npz_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None)
     return save_path
 
 
-def defend_npz_train_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None) -> str:
+def defend_npz_train_test_data(r: Restorer, path: str, args: DefenseArgs, defend=None, save_model=None) -> str:
     """opt_defense.py:347-369 (--train=True): train_pc/train_label/test_pc/test_label."""
     npz = np.load(path)
     fn = defend or (lambda a: defend_point_cloud(r, a, args))
     def_train = fn(npz['train_pc'][..., :3])
     def_test = fn(npz['test_pc'][..., :3])
-    save_path = get_save_name(path, getattr(r, 'model_name', 'convonet'))
+    save_path = get_save_name(path, save_model or getattr(r, 'model_name', 'convonet'))
     np.savez(save_path, train_pc=def_train.astype(np.float32), train_label=npz['train_label'].astype(np.uint8),
              test_pc=def_test.astype(np.float32), test_label=npz['test_label'].astype(np.uint8))
     print('defense result saved to {}'.format(save_path))

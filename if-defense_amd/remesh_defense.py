@@ -1,0 +1,91 @@
+"""Reconstruct a mesh with the Occupancy Network and re-sample its surface - MI355X build of ONet/remesh_defense.py.
+
+Same flags, defaults and .npz in/out as the reference CLI (ONet/remesh_defense.py:19-41,173-285; output
+<dir>/ONet-Mesh/onet_remesh-<name>):
+
+    python -m ifdefense_amd.remesh_defense --data_root=path/to/adv_data.npz
+
+Additions: --seed (surface samples and the 300-point subset are counter-based draws; the reference is unseeded),
+--weights.  Under torchrun the clouds of each file are sharded over the ranks and all-gathered (rank 0 writes).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from .opt_defense import check_supported, load_config, str2bool
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Extract meshes from occupancy process.')
+    parser.add_argument('--config', type=str, default='configs/onet_mn40.yaml', help='Path to config file.')
+    parser.add_argument('--sample_npoint', type=int, default=1024, help='Re-sample points number per mesh.')
+    parser.add_argument('--padding_scale', type=float, default=0.9,
+                        help='Used in pre-processing point clouds, padding in unit cube')
+    parser.add_argument('--data_root', type=str, default='', help='Path to point cloud npz file.')
+    parser.add_argument('--train', type=str2bool, default=False, help='whether defend training data')
+    parser.add_argument('--sor', type=str2bool, default=True, help='whether use SOR before reconstruction')
+    parser.add_argument('--sor_k', type=int, default=2, help='KNN in SOR')
+    parser.add_argument('--sor_alpha', type=float, default=1.1, help='Threshold = mean + alpha * std')
+    parser.add_argument('--seed', type=int, default=0, help='seed of the counter-based random draws')
+    parser.add_argument('--weights', type=str, default='', help='checkpoint (.pth); default: cfg test.model_file')
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    cfg = load_config(args.config, 'configs/default.yaml', "onet")
+    check_supported(cfg, "onet")
+    gen = cfg.get('generation', {}) or {}
+    if gen.get('resolution_0', 32) != 32 or gen.get('upsampling_steps', 2) != 2 or gen.get('refinement_step', 0) != 0 or \
+            gen.get('simplify_nfaces') is not None:
+        raise SystemExit("unsupported generation config: only resolution_0 32 / upsampling_steps 2 without refinement or "
+                         "simplification (configs/default.yaml:64-74) is built for MI355X")
+
+    import torch
+    from . import DefenseArgs, OnetRestorer, defend_npz_test_data, remesh_point_cloud, weights, get_save_name
+    from . import dist as D
+
+    rank, world, local = D.init_from_env()
+    r = OnetRestorer(weights.load_checkpoint(args.weights or cfg['test']['model_file'], "onet"),
+                     device=torch.device('cuda', local), threshold=cfg['test']['threshold'])
+    dargs = DefenseArgs(sample_npoint=args.sample_npoint, padding_scale=args.padding_scale, sor=args.sor, sor_k=args.sor_k,
+                        sor_alpha=args.sor_alpha, threshold=cfg['test']['threshold'], input_npoint=cfg['data']['pointcloud_n'],
+                        seed=args.seed)
+
+    def defend(pc, normalize=True):
+        out = D.defend_sharded(lambda shard, base, total: remesh_point_cloud(r, shard, dargs, base, return_device=True,
+                                                                            normalize=normalize), pc)
+        return out.cpu().numpy()
+
+    def one_file(path):
+        if args.train:                                            # remesh_defense.py:187-223 (train split not normalised)
+            npz = np.load(path)
+            tr = defend(npz['train_pc'][..., :3], normalize=False)
+            te = defend(npz['test_pc'][..., :3])
+            if rank == 0:
+                save_path = get_save_name(path, "onet-mesh")
+                np.savez(save_path, train_pc=tr.astype(np.float32), test_pc=te.astype(np.float32),
+                         train_label=npz['train_label'], test_label=npz['test_label'])
+                print('defense result saved to {}'.format(save_path))
+        elif rank == 0:
+            defend_npz_test_data(r, path, dargs, defend=defend, save_model="onet-mesh")
+        else:
+            defend(np.load(path)['test_pc'][..., :3])
+
+    data_root = args.data_root
+    if not args.train and os.path.isdir(data_root):
+        for file in sorted(os.listdir(data_root)):
+            one = os.path.join(data_root, file)
+            if os.path.isfile(one):
+                one_file(one)
+    else:
+        one_file(data_root)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

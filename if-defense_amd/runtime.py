@@ -241,6 +241,7 @@ class Restorer:
         self._check(self.lib.ifd_get_counters(self.ctx, buf, 16))
         return {"knn_rebuilds": int(buf[0]), "knn_brute_scans": int(buf[1]), "knn_passes": int(buf[2]),
                 "cloud0_shader_cycles": int(buf[3]), "knn_ring_evals": int(buf[4]), "knn_exact_evals": int(buf[5]), "knn_refresh_waves": int(buf[6]), "knn_lists_built": int(buf[7]),
+                "mesh_points": int(buf[8]), "mesh_rounds": int(buf[9]),
                 "prof_cycles": [int(buf[i]) for i in range(8, 16)]}      # only in -DIFD_PROF diagnostic builds
 
     def normalize_batch_pc(self, points: torch.Tensor) -> torch.Tensor:

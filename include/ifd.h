@@ -186,7 +186,8 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
  * radii + re-passes for overflowed balls), [3] shader-clock cycles cloud 0 spent in the optimiser kernel
  * (effective clock = cycles / kernel time), [4] wave-steps that had to evaluate the back ring of the lists,
  * [5] wave-steps on the exact insertion path (near-ties, loss-reporting step), [6] wave-steps with individual
- * list refreshes, [7] lists built in total.  n <= IFD_N_COUNTERS. */
+ * list refreshes, [7] lists built in total; of the most recent ifd_onet_mesh_sample: [8] grid points evaluated,
+ * [9] MISE rounds (summed over chunks).  n <= IFD_N_COUNTERS. */
 #define IFD_N_COUNTERS 16
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
 

@@ -700,3 +700,59 @@ def test_onet_mesh_grid_and_surface_match_reference_libs(onet, og, res0, steps):
     again = onet.mesh_sample(c[1:], n_sample=1024, resolution0=res0, upsampling_steps=steps, seed=3, cloud_index_base=1,
                              threshold=MESH_THRESHOLD)
     assert torch.equal(again["points"][0], out["points"][1])
+
+
+def test_onet_mesh_driver_and_cli(onet, tmp_path):
+    """remesh_point_cloud (ONet/remesh_defense.py:228-262) + the CLI: output schema, unit-sphere normalisation,
+    sharding invariance, and the empty-mesh fallback."""
+    import subprocess, sys, os
+    import bench
+    import ifdefense_amd as I
+    clouds = bench.synth_clouds(6)
+    args = I.DefenseArgs(input_npoint=300, seed=4)
+    full = I.remesh_point_cloud(onet, clouds, args)
+    assert full.shape == (6, 1024, 3) and full.dtype == np.float32 and np.isfinite(full).all()
+    np.testing.assert_allclose(np.linalg.norm(full, axis=-1).max(axis=1), 1.0, rtol=1e-6)
+    lo = I.remesh_point_cloud(onet, clouds[:2], args, cloud_index_base=0)
+    hi = I.remesh_point_cloud(onet, clouds[2:], args, cloud_index_base=2)
+    assert np.array_equal(np.concatenate([lo, hi]), full)
+    # empty mesh (threshold above every occupancy): the reference falls back to the (post-SOR) input points
+    onet_hi = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device="cuda:0",
+                             threshold=0.999)
+    fb = I.remesh_point_cloud(onet_hi, clouds[:2], I.DefenseArgs(input_npoint=300, seed=4, sor=False))
+    ref = clouds[:2] - clouds[:2].mean(1, keepdims=True)
+    ref = ref / np.linalg.norm(ref, axis=-1).max(1)[:, None, None]
+    np.testing.assert_allclose(fb, ref, atol=1e-6)
+    onet_hi.close()
+    # CLI
+    wpath = tmp_path / "onet.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in I.weights.onet_random_state_dict(0).items()}, wpath)
+    src = tmp_path / "adv.npz"
+    np.savez(src, test_pc=clouds[:3], test_label=np.array([1, 2, 3]), target_label=np.array([4, 5, 6]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "ifdefense_amd.remesh_defense", "--data_root", str(src), "--weights", str(wpath)],
+                       capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(tmp_path / "ONet-Mesh" / "onet_remesh-adv.npz")
+    assert sorted(z.files) == ["target_label", "test_label", "test_pc"]
+    assert z["test_pc"].shape == (3, 1024, 3) and z["test_pc"].dtype == np.float32 and z["target_label"].dtype == np.uint8
+
+
+def test_onet_mesh_samples_match_oracle_distribution(onet, og):
+    """End of the mesh path: the surface samples are random draws (unseeded in the reference), so compare
+    distributions - symmetric Chamfer distance between HIP samples and the CPU oracle's (reference MISE + libmcubes
+    around the oracle decoder) against the oracle's own seed-to-seed Chamfer distance."""
+    _ref_libs()
+    from oracle import mesh_oracle as MO
+    from oracle import onet_oracle as OO
+    ow = OO.to_torch(OO.make_random_weights(0))
+    c = torch.from_numpy(og["c"][:1])
+    thr = _cutting_threshold(onet, c)
+    grid, t = MO.occupancy_grid(ow, c[0], resolution0=16, upsampling_steps=1, threshold=thr)
+    v, f = MO.extract_mesh(grid, t)
+    a = MO.sample_surface(v, f, 1024, np.random.default_rng(0)).astype(np.float32)
+    b = MO.sample_surface(v, f, 1024, np.random.default_rng(1)).astype(np.float32)
+    hip = onet.mesh_sample(c, resolution0=16, upsampling_steps=1, threshold=thr, seed=5)["points"][0].cpu().numpy()
+    cd_self, cd_hip = _chamfer(a, b), 0.5 * (_chamfer(hip, a) + _chamfer(hip, b))
+    print("ONet-Mesh samples: Chamfer HIP<->oracle %.4f, oracle seed<->seed %.4f" % (cd_hip, cd_self))
+    assert cd_hip < 1.15 * cd_self

@@ -76,3 +76,27 @@ def test_end_to_end_11_steps(og, ow, golden):
     out = OO.optimize_points(ow, torch.from_numpy(golden["init_points"]), torch.from_numpy(og["c"]), iterations=10)
     d = np.linalg.norm(out.numpy() - og["e2e10_out"], axis=-1)
     assert d.max() < 1e-3 and np.median(d) < 1e-5
+
+
+def test_mesh_oracle_surface_sampling_and_reference_libs():
+    """oracle/mesh_oracle.py: the restated trimesh.sample.sample_surface is area-uniform, and (when oracle/_ref is
+    built) the reference MISE + libmcubes reproduce a sphere's area."""
+    from oracle import mesh_oracle as MO
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [3, 0, 0], [3, 1, 0]], np.float64)
+    f = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 5], [1, 5, 2]])            # unit square + a 2 x 1 rectangle
+    s = MO.sample_surface(v, f, 30000, np.random.default_rng(0))
+    assert (s[:, 2] == 0).all() and s[:, 0].min() >= 0 and s[:, 0].max() <= 3 and s[:, 1].min() >= 0 and s[:, 1].max() <= 1
+    assert abs((s[:, 0] < 1).mean() - 1 / 3) < 0.01                     # area-weighted
+    try:
+        mise, mcubes = MO.ref_libs()
+    except ImportError:
+        pytest.skip("oracle/_ref not built")
+    m = mise.MISE(8, 2, 0.0)
+    pts = m.query()
+    while pts.shape[0]:
+        m.update(pts, (0.3 - np.linalg.norm(pts / m.resolution - 0.5, axis=1)).astype(np.float64))
+        pts = m.query()
+    vert, tri = MO.extract_mesh(m.to_dense(), 0.0, padding=0.0)
+    t = vert[tri]
+    area = 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum()
+    assert abs(area - 4 * np.pi * 0.09) / (4 * np.pi * 0.09) < 0.03
