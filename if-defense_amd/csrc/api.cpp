@@ -454,11 +454,9 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
-    OptArgs a;
+    OptArgs a{};
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
     a.knn_scan_every_step = prm->knn_scan_every_step;
-    { const char* d = getenv("IFD_SHARED_PLANES"); a.shared_planes = d ? atoi(d) : 0; }
-    { const char* d = getenv("IFD_OPT_VARIANT"); a.variant = d ? atoi(d) : 2; }
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;

@@ -8,10 +8,6 @@ namespace ifd {
 
 struct OptArgs {
     int steps, t0, loss_batch, normalize, knn_scan_every_step;
-    int shared_planes;   // experiment hook (env IFD_SHARED_PLANES): every cloud reads cloud 0's planes
-    int variant;         // decoder-tile schedule (env IFD_OPT_VARIANT): 0 = one 16-point tile, taps held in registers;
-                         // 1 = two 16-point sub-tiles in lock-step, taps re-gathered; 2 (default) = 1 + software-pipelined
-                         // (one sub-tile's MFMAs interleaved with the other's epilogue, weights prefetched a layer ahead)
     float lr, rep_weight, threshold, rep_radius, rep_h, rep_eps;
     DecConst dc;
 };

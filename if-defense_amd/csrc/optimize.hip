@@ -342,7 +342,7 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two 16-point sub-tiles per wave, processed in lock-step (the optimiser's phase A).
+// Two 16-point sub-tiles per wave (the optimiser's decoder tile; helpers shared by decoder_tile3 below).
 //   * 4 independent accumulator chains per layer (2 sub-tiles x 2 M-tiles): no dependent-MFMA stalls, and the
 //     VALU epilogue of one sub-tile (bias, ReLU, mask) overlaps the other sub-tile's MFMAs;
 //   * every A operand (weight) is fetched from LDS once and feeds both sub-tiles: half the LDS reads per MFMA;
@@ -377,255 +377,8 @@ __device__ __forceinline__ void sub_geometry(SubGeo& g, float x0, float x1, floa
     }
 }
 
-// two sub-tiles, shared A operands: 32 MFMAs per layer, 16 LDS reads
-template <bool TRANSPOSED>
-__device__ __forceinline__ void dense32x2(const float* __restrict__ wl, const LaneOff& lo, const f32x8& in0,
-                                          const f32x8& in1, Acc2& acc0, Acc2& acc1) {
-    const float* base = wl + (TRANSPOSED ? lo.bwd : lo.fwd);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int mtp = s >> 2, rp = s & 3;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + 16 * mt) : (16 * mt * W_STRIDE + 16 * mtp + 4 * rp);
-            const float a = base[off];
-            acc0.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in0[s], acc0.t[mt], 0, 0, 0);
-            acc1.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in1[s], acc1.t[mt], 0, 0, 0);
-        }
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void decoder_tile2(const float* __restrict__ W, const float* __restrict__ planes,
-                                              const f32x4 xa, const f32x4 xb, int lane, const DecConst dc, float thr,
-                                              float inv_lb, float (&bce)[2], float (&dx)[2][3]) {
-    const int n = lane & 15, q = lane >> 4;
-    LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
-    asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
-    constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
-    SubGeo geo[2];
-    sub_geometry(geo[0], xa.x, xa.y, xa.z, dc);
-    sub_geometry(geo[1], xb.x, xb.y, xb.z, dc);
-
-    // ---- gather + forward bilinear sample, one plane (2 x 8 loads) at a time ---------------------------------
-    f32x8 c[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
-#pragma unroll
-    for (int P = 0; P < 3; ++P) {
-        const int a0 = AX0[P], a1 = AX1[P];
-        f32x4 tap[2][4][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float* qp = planes + ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
-                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
-                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
-                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const SubGeo& g = geo[t];
-            const float wnw = g.w0[a0] * g.w0[a1], wne = g.w1[a0] * g.w0[a1], wsw = g.w0[a0] * g.w1[a1],
-                        wse = g.w1[a0] * g.w1[a1];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float s = tap[t][0][mt][j] * wnw;
-                    s = fmaf(tap[t][1][mt][j], wne, s);
-                    s = fmaf(tap[t][2][mt][j], wsw, s);
-                    s = fmaf(tap[t][3][mt][j], wse, s);
-                    c[t][4 * mt + j] += s;
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- forward MLP ----------------------------------------------------------------------------------------
-    Acc2 net[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                net[t].t[mt][j] = fmaf(wp.z, geo[t].x[2], fmaf(wp.y, geo[t].x[1], fmaf(wp.x, geo[t].x[0], wp.w)));
-        }
-    uint32_t mask_a[2][NBLK], mask_h[2][NBLK];
-    const float* Wd = W + DEC_OFF_W;
-#pragma unroll
-    for (int i = 0; i < NBLK; ++i) {
-        const float* Wl = Wd + 3 * i * W_LAYER;
-        Acc2 a[2], h[2], o[2];
-        {
-            const Acc2 b = load_bias(W, 3 * i, lo);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { a[t].t[0] = b.t[0] + net[t].t[0]; a[t].t[1] = b.t[1] + net[t].t[1]; }
-        }
-        dense32x2<false>(Wl, lo, c[0], c[1], a[0], a[1]);                       // a_i = n_i + fc_c[i](c)
-        f32x8 ra[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x8 af = flat(a[t]);
-            mask_a[t][i] = mask_pos_packed(af);
-            ra[t] = relu8(af);
-        }
-        {
-            const Acc2 b = load_bias(W, 3 * i + 1, lo);
-            h[0] = b; h[1] = b;
-        }
-        dense32x2<false>(Wl + W_LAYER, lo, ra[0], ra[1], h[0], h[1]);          // fc_0(relu(a))
-        f32x8 rh[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x8 hf = flat(h[t]);
-            mask_h[t][i] = mask_pos_packed(hf);
-            rh[t] = relu8(hf);
-        }
-        {
-            const Acc2 b = load_bias(W, 3 * i + 2, lo);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { o[t].t[0] = b.t[0] + a[t].t[0]; o[t].t[1] = b.t[1] + a[t].t[1]; }
-        }
-        dense32x2<false>(Wl + 2 * W_LAYER, lo, rh[0], rh[1], o[0], o[1]);      // a + fc_1(relu(h))
-        net[0] = o[0];
-        net[1] = o[1];
-        __builtin_amdgcn_sched_barrier(0);      // one block at a time: bounds the weight-load hoisting
-    }
-    f32x8 wout;
-    {
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + lo.q4);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
-    }
-    f32x8 dn[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x8 nf = flat(net[t]);
-        float part = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) part = fmaf(wout[r], fmaxf(nf[r], 0.f), part);
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        const float logit = part + W[DEC_OFF_BOUT];
-        float dl;
-        if (MODE == MODE_OPT) {
-            const float e = expf(-fabsf(logit));
-            bce[t] = fmaxf(logit, 0.f) - thr * logit + log1pf(e);
-            const float sig = logit >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-            dl = (sig - thr) * inv_lb;
-        } else {
-            bce[t] = logit;                   // MODE_SUM: report the logit, gradient of sum(logits)
-            dl = 1.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) dn[t][r] = nf[r] > 0.f ? dl * wout[r] : 0.f;
-    }
-
-    // ---- backward (parameters frozen: only the path to the input) -----------------------------------------------
-    Acc2 dcc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { dcc[t].t[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dcc[t].t[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int i = NBLK - 1; i >= 0; --i) {
-        const float* Wl = Wd + 3 * i * W_LAYER;
-        Acc2 z[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { z[t].t[0] = f32x4{0.f, 0.f, 0.f, 0.f}; z[t].t[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        dense32x2<true>(Wl + 2 * W_LAYER, lo, dn[0], dn[1], z[0], z[1]);       // fc_1^T dn
-        f32x8 dh[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            dh[t] = flat(z[t]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) dh[t][r] = ((mask_h[t][i] >> r) & 1u) ? dh[t][r] : 0.f;
-            z[t].t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            z[t].t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        dense32x2<true>(Wl + W_LAYER, lo, dh[0], dh[1], z[0], z[1]);           // fc_0^T dh
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x8 tt = flat(z[t]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) dn[t][r] += ((mask_a[t][i] >> r) & 1u) ? tt[r] : 0.f;   // delta a_i
-        }
-        dense32x2<true>(Wl, lo, dn[0], dn[1], dcc[0], dcc[1]);                 // dc += fc_c^T da
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    float g[2][3];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float d = dn[t][4 * mt + j];
-                g[t][0] = fmaf(wp.x, d, g[t][0]); g[t][1] = fmaf(wp.y, d, g[t][1]); g[t][2] = fmaf(wp.z, d, g[t][2]);
-            }
-        }
-    // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
-    f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
-#pragma unroll
-    for (int P = 0; P < 3; ++P) {
-        const int a0 = AX0[P], a1 = AX1[P];
-        f32x4 tap[2][4][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int off = ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
-            asm volatile("" : "+v"(off));      // opaque: do not CSE with (and keep alive since) the forward gather
-            const float* qp = planes + off;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
-                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
-                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
-                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const SubGeo& gg = geo[t];
-            float dnw = 0.f, dne = 0.f, dsw = 0.f, dse = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = dcf[t][4 * mt + j];
-                    dnw = fmaf(tap[t][0][mt][j], d, dnw); dne = fmaf(tap[t][1][mt][j], d, dne);
-                    dsw = fmaf(tap[t][2][mt][j], d, dsw); dse = fmaf(tap[t][3][mt][j], d, dse);
-                }
-            const float gix = (dne - dnw) * gg.w0[a1] + (dse - dsw) * gg.w1[a1];
-            const float giy = (dsw - dnw) * gg.w0[a0] + (dse - dne) * gg.w1[a0];
-            const float sc = (0.5f * (float)(RES - 1)) * 2.f;
-            g[t][a0] += gg.live[a0] * ((gix * sc) / dc.sdiv);
-            g[t][a1] += gg.live[a1] * ((giy * sc) / dc.sdiv);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float v = g[t][a];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            dx[t][a] = v;
-        }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Software-pipelined version of the two-sub-tile schedule (SCHED = 2).
+// The two-sub-tile schedule, software-pipelined (32 MFMAs per layer, 16 LDS reads - every A operand feeds both).
 //   region k.1 :  16 MFMAs of sub-tile 0, layer k   ||  VALU epilogue (bias/ReLU/mask) of sub-tile 1, layer k-1
 //   region k.2 :  16 MFMAs of sub-tile 1, layer k   ||  VALU epilogue of sub-tile 0, layer k  ||  LDS prefetch of
 //                 layer k+1's 16 A operands + bias into registers
@@ -952,13 +705,12 @@ __device__ __forceinline__ void load_dec_image(float* __restrict__ W, const floa
 // ---------------------------------------------------------------------------------------------
 // NW waves per workgroup (8: 2 per SIMD / 256 VGPRs, 12: 3 per SIMD / 168 VGPRs); threads [0,512) own two points
 // each (kNN + Adam duty), every wave pulls 16-point decoder tiles from an LDS counter.
-template <int NW, int SCHED>
+template <int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
     float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
     const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
     unsigned long long* __restrict__ counters, int K, OptArgs A) {
-    constexpr bool HOLD = SCHED == 0;                    // single 16-point tiles (else 32-point super-tiles)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
     f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
@@ -968,11 +720,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 
     const int cloud = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* pl = planes + (A.shared_planes ? (size_t)0 : (size_t)cloud * CLOUD_PLANE_FLOATS);
+    const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
     float* pc = p + (size_t)cloud * K * 3;
     const bool owner = tid < OPT_THREADS;
     const int pa = owner ? tid : MAXK, pb = owner ? tid + OPT_THREADS : MAXK;   // the two points this thread owns
-    const int ntiles = HOLD ? (K + 15) >> 4 : (K + 31) >> 5;          // HOLD: 16-point tiles, else 32-point super-tiles
+    const int ntiles = (K + 31) >> 5;                                 // 32-point tiles (two 16-point sub-tiles)
 
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
@@ -1045,24 +797,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 if (lane == 0) tile = atomicAdd(tile_ctr, 1);
                 tile = __shfl(tile, 0);
                 if (tile >= ntiles) break;
-                if (HOLD) {          // one 16-point tile, taps held in registers
-                    const int tp = min(tile * 16 + (lane & 15), K - 1);
-                    const f32x4 x = X[tp];
-                    float logit, bce, dx[3];
-                    decoder_tile<MODE_OPT, true, 1>(W, pl, x.x, x.y, x.z, lane, dc, A.threshold, inv_lb, logit, bce, dx);
-                    if (lane < 16 && tile * 16 + lane < K) G[tp] = f32x4{dx[0], dx[1], dx[2], bce};
-                } else {             // two 16-point sub-tiles in lock-step
-                    const int ia = tile * 32 + (lane & 15), ib = ia + 16;
-                    const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
-                    float bce[2], dx[2][3];
-                    if (SCHED == 2)
-                        decoder_tile3<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
-                    else
-                        decoder_tile2<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
-                    if (lane < 16) {
-                        if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
-                        if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
-                    }
+                const int ia = tile * 32 + (lane & 15), ib = ia + 16;    // two 16-point sub-tiles, software-pipelined
+                const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
+                float bce[2], dx[2][3];
+                decoder_tile3<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
+                if (lane < 16) {
+                    if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
+                    if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
                 }
             }
             PROF_ACC(pc_tiles);
@@ -1237,16 +978,9 @@ static_assert(OPT_LDS <= 160 * 1024, "LDS budget");
 size_t knn_list_bytes(int B) { return (size_t)B * MAXK * LIST_M * sizeof(uint16_t); }
 
 hipError_t configure_optimize_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 0>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
-    if (e != hipSuccess) return e;
-
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
     return e;
@@ -1255,15 +989,8 @@ hipError_t configure_optimize_kernels() {
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
                            float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
                            unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s) {
-    if (a.variant == 2)
-        hipLaunchKernelGGL((optimize_kernel<8, 2>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                           loss_batch_per_cloud, knn_lists, counters, K, a);
-    else if (a.variant == 1)
-        hipLaunchKernelGGL((optimize_kernel<8, 1>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                           loss_batch_per_cloud, knn_lists, counters, K, a);
-    else
-        hipLaunchKernelGGL((optimize_kernel<8, 0>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                           loss_batch_per_cloud, knn_lists, counters, K, a);
+    hipLaunchKernelGGL((optimize_kernel<8>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
+                       loss_batch_per_cloud, knn_lists, counters, K, a);
     return hipGetLastError();
 }
 
