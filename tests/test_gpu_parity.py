@@ -112,6 +112,34 @@ def test_p1_teacher_forced_single_steps(restorer, golden, planes2):
     print("P1: coordinates off by > 1e-6 over 4 teacher-forced steps:", flips, "of", 4 * 2 * 1024 * 3)
 
 
+def test_p1_late_steps_t100_t500_and_loss_batch(restorer, golden, planes2, oracle_weights):
+    """G4 at Adam t = 100 and 500 (fixtures from a 500-step run of the reference), and the 1/B loss factor at the
+    reference batch size 192 (G3) against the oracle."""
+    import os
+    from oracle import convonet_oracle as O
+    gl = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convonet_golden_long.npz"))
+    for t in (99, 499):
+        state = (torch.from_numpy(gl[f"traj{t}_m"]), torch.from_numpy(gl[f"traj{t}_v"]), t)
+        out, loss = restorer.optimize_points(torch.from_numpy(gl[f"traj{t}_x"]), planes2, rep_weight=500.0, steps=1,
+                                             state=state, normalize=False, return_loss=True)
+        d = np.abs(out.cpu().numpy() - gl[f"traj{t}_x_next"])
+        assert (d > 1e-6).mean() < 2e-3, (t, float(d.max()), int((d > 1e-6).sum()))
+        loss = loss.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(loss[:, 0].sum() / 2, gl[f"traj{t}_loss"][0], rtol=1e-5)
+        np.testing.assert_allclose(loss[:, 1].mean() * 500.0, gl[f"traj{t}_loss"][1], rtol=1e-4)
+    x = torch.from_numpy(golden["traj9_x"])
+    m, v = torch.from_numpy(golden["traj9_m"]), torch.from_numpy(golden["traj9_v"])
+    for lb in (1, 192):
+        xr = x.clone().requires_grad_()
+        total, _, _, _ = O.losses(oracle_weights, xr, planes2, 500.0, loss_batch=lb)
+        total.backward()
+        ref, _, _ = O.adam_step(x, xr.grad, m, v, 10)
+        got = restorer.optimize_points(x, planes2, rep_weight=500.0, steps=1, state=(m, v, 9), normalize=False,
+                                       loss_batch=lb)
+        d = np.abs(got.cpu().numpy() - ref.numpy())
+        assert (d > 1e-6).mean() < 2e-3, (lb, float(d.max()))
+
+
 def test_p2_free_running_10_and_50_steps(restorer, golden, planes2):
     init = torch.from_numpy(golden["init_points"][:2])
     x10 = restorer.optimize_points(init, planes2, rep_weight=500.0, steps=10, normalize=False)

@@ -135,3 +135,21 @@ def test_end_to_end_20(golden, oracle_weights):
     d = (out - torch.from_numpy(golden["e2e20_out"])).norm(dim=-1)
     # 21 chaotic steps: bulk must agree tightly, a few points may have diverged
     assert float(d.median()) < 1e-4 and float((d > 1e-2).float().mean()) < 0.01, (float(d.median()), float(d.max()))
+
+
+def test_oracle_late_teacher_forced_steps(oracle_weights, golden):
+    """G4 at Adam t = 100 and 500: the oracle's gradient and update from the reference's recorded state."""
+    import os
+    from oracle import convonet_oracle as O
+    gl = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convonet_golden_long.npz"))
+    planes2 = {pl: torch.from_numpy(golden["planes01"][:, i]) for i, pl in enumerate(("xz", "xy", "yz"))}
+    for t in (99, 499):
+        x = torch.from_numpy(gl[f"traj{t}_x"]).clone().requires_grad_()
+        total, occ, rep, _ = O.losses(oracle_weights, x, planes2, 500.0)
+        total.backward()
+        dg = np.abs(x.grad.numpy() - gl[f"traj{t}_g"]) / np.abs(gl[f"traj{t}_g"]).max()
+        assert (dg > 2e-5).mean() < 1e-3 and dg.max() < 2e-2, dg.max()
+        np.testing.assert_allclose([float(occ.detach()), float(rep.detach())], gl[f"traj{t}_loss"], rtol=1e-4)
+        xn, _, _ = O.adam_step(x.detach(), torch.from_numpy(gl[f"traj{t}_g"]), torch.from_numpy(gl[f"traj{t}_m"]),
+                               torch.from_numpy(gl[f"traj{t}_v"]), t + 1)
+        assert np.abs(xn.numpy() - gl[f"traj{t}_x_next"]).max() < 1e-6
