@@ -143,9 +143,13 @@ def test_world2_gloo_shard_and_allgather(tmp_path):
         "out = D.defend_sharded(f, pc)\n"
         "assert out.shape == (7, 5, 3) and np.array_equal(out.numpy(), pc * 2), out\n"
         "print('rank', rank, 'of', world, 'ok')\n" % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653")
+    import socket
+    with socket.socket() as sk:                 # a free port (a fixed one fails when two test runs follow each other)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29653", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 of 2 ok" in r.stdout and "rank 1 of 2 ok" in r.stdout
