@@ -458,9 +458,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
     sub_geometry(geo[1], xb.x, xb.y, xb.z, dc);
     const float* Wd = W + DEC_OFF_W;
 
-    // weights of the first layer ride along with the gather
-    WFrag A = load_wfrag<false>(Wd, lo);
-    Acc2 B = load_bias(W, 0, lo);
 
     // ---- gather + forward bilinear sample, one plane (2 x 8 loads) at a time ---------------------------------
     f32x8 c[2];
@@ -468,8 +465,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
-    // Two planes in flight: the taps come from HBM / Infinity Cache (L2 hit rate 37 %), one round trip per plane would
-    // cost ~1.5 us each - the loads of plane P + 1 are issued before plane P is consumed (2 x 64 tap registers).
+    // The taps come from HBM / Infinity Cache (L2 hit rate 37 %): one round trip per plane would cost ~1.5 us each, so
+    // the loads of several planes are in flight at once (64 tap registers per plane).
     auto load_taps = [&](int P, f32x4 (&tap)[2][4][2], bool opaque) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -509,10 +506,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         f32x4 tap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
         load_taps(0, tap0, false);
         load_taps(1, tap1, false);
+        load_taps(2, tap2, false);               // all three planes in flight (192 registers; nothing else is live yet)
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(0, tap0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_taps(2, tap2, false);
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(1, tap1);
         __builtin_amdgcn_sched_barrier(0);
@@ -520,6 +516,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    WFrag A = load_wfrag<false>(Wd, lo);         // weights of the first layer (after the gather: its registers are free now)
+    Acc2 B = load_bias(W, 0, lo);
     Acc2 net[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -687,11 +685,13 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         }
     };
     {
-        f32x4 tap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
-        load_taps(0, tap0, true);
+        // two planes in flight (three spill here, and starting the re-gather under the last MLP block does too:
+        // both measured slower)
+        f32x4 btap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
+        load_taps(0, btap0, true);
         load_taps(1, tap1, true);
         __builtin_amdgcn_sched_barrier(0);
-        sample_bwd(0, tap0);
+        sample_bwd(0, btap0);
         __builtin_amdgcn_sched_barrier(0);
         load_taps(2, tap2, true);
         __builtin_amdgcn_sched_barrier(0);
