@@ -474,8 +474,10 @@ int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
     unsigned long long tmp[IFD_N_COUNTERS] = {0};
     hipError_t e = hipMemcpy(tmp, ctx->d_counters, sizeof(tmp), hipMemcpyDeviceToHost);   // synchronises
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_get_counters", e);
-    tmp[8] = ctx->mesh_points;     // host-side tallies of the last ifd_onet_mesh_sample
-    tmp[9] = ctx->mesh_rounds;
+    if (ctx->model == IFD_MODEL_ONET) {   // host-side tallies of the last ifd_onet_mesh_sample
+        tmp[8] = ctx->mesh_points;
+        tmp[9] = ctx->mesh_rounds;
+    }
     for (int i = 0; i < n; ++i) out_host[i] = i < IFD_N_COUNTERS ? tmp[i] : 0;
     return IFD_OK;
 }
