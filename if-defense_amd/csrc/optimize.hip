@@ -795,10 +795,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
         long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
-        // Work of one step: ntiles decoder tiles (pulled from an LDS counter by every wave) + the kNN/repulsion of
-        // the 8 owner waves.  Waves 4-7 do their kNN first, waves 0-3 after a few tiles, so that each SIMD always
-        // has MFMA work queued next to the VALU-only kNN; waves >= 8 (3-per-SIMD configuration) only pull tiles.
-        const int quota = wave < 4 ? (ntiles + 2 * NW - 1) / (2 * NW) : 0;
+        // Work of one step: the kNN / repulsion of the points each wave owns, then ntiles decoder tiles pulled from an
+        // LDS counter.  Every wave runs its kNN phase FIRST, all at the same time (quota = 0 tiles before it): pairing
+        // a VALU-only kNN wave with an MFMA-heavy tile wave on a SIMD - the first design, quota = ntiles / 16 for
+        // waves 0-3 - buys nothing, because MFMA and VALU issue do not overlap on gfx950, and starves the VALU wave
+        // (measured: 249 -> 233 us per step).  The two-pass loop shape is kept on purpose: hipcc's code for the flat
+        // form (kNN, then one tile loop) measured 239-243 us.
+        const int quota = 0;
 #pragma unroll 1
         for (int phase = 0; phase < 2; ++phase) {
             if (phase == 1 && wave < OWN_WAVES && use_rep) {
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                           ksh, rc, rep_loss_a, rep_loss_b, gca, gcb, cn);
             }
             PROF_T0();
-            // decoder tiles: phase 0 = up to `quota` tiles before the kNN, phase 1 = until the step's tiles run out
+            // decoder tiles: pass 0 = up to `quota` tiles before the kNN, pass 1 = until the step's tiles run out
 #pragma unroll 1
             for (int n = 0; phase == 1 || n < quota; ++n) {
                 int tile = 0;
