@@ -459,8 +459,9 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
             dmax = fmaxf(dmax, dmaxbuf[(step & 1) * MAX_WAVES + w]);
             mv = fmaxf(mv, movebuf[(step & 1) * MAX_WAVES + w]);
         }
-        // the certificate must survive one more step: r5 grows <= 2 mv, both displacements <= mv
-        const float soft_slack = 6.f * mv;
+        // the certificate must survive one more step: r5 grows <= 2 mv, own and the others' displacement <= mv each
+        // (mv = largest move of the step just taken; a larger next move only costs an exact scan, never correctness)
+        const float soft_slack = 4.f * mv;
         PROF_T0();
         const bool need_a = pa < K && (force || ka.pend), need_b = pb < K && (force || kb.pend);
         if (__any(need_a || need_b)) {
