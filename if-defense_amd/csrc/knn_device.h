@@ -22,19 +22,23 @@ __device__ __forceinline__ void top5_init(Top5& t) {
     t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0;
 }
 
-// Branch-free sorted insertion (bubble the new key down with selects).  NOTE: the obvious nested-ternary
-// form is turned into exec-mask control flow by hipcc (4x the code, I-cache thrash) - keep this shape.
-__device__ __forceinline__ void top5_insert_nb(Top5& t, float d, int j) {
+// Branch-free sorted insertion (bubble the new key down with selects).  NOTE: the obvious nested-ternary form is turned
+// into exec-mask control flow by hipcc (4x the code, I-cache thrash) - keep this shape.  Ties in d are broken by the
+// smaller index.  Exact ties DO occur (clamped coordinates on flat faces), and
+// every path - the scan, the exact list path, the key path via its ambiguity check - must pick the same neighbour:
+// the 5 smallest (distance, index) pairs.
+__device__ __forceinline__ void top5_insert_lex(Top5& t, float d, int j) {
     bool c; float lo; int li;
-    c = d < t.d0; lo = c ? d : t.d0; li = c ? j : t.i0; d = c ? t.d0 : d; j = c ? t.i0 : j; t.d0 = lo; t.i0 = li;
-    c = d < t.d1; lo = c ? d : t.d1; li = c ? j : t.i1; d = c ? t.d1 : d; j = c ? t.i1 : j; t.d1 = lo; t.i1 = li;
-    c = d < t.d2; lo = c ? d : t.d2; li = c ? j : t.i2; d = c ? t.d2 : d; j = c ? t.i2 : j; t.d2 = lo; t.i2 = li;
-    c = d < t.d3; lo = c ? d : t.d3; li = c ? j : t.i3; d = c ? t.d3 : d; j = c ? t.i3 : j; t.d3 = lo; t.i3 = li;
-    c = d < t.d4; t.d4 = c ? d : t.d4; t.i4 = c ? j : t.i4;
+    c = d < t.d0 || (d == t.d0 && j < t.i0); lo = c ? d : t.d0; li = c ? j : t.i0; d = c ? t.d0 : d; j = c ? t.i0 : j; t.d0 = lo; t.i0 = li;
+    c = d < t.d1 || (d == t.d1 && j < t.i1); lo = c ? d : t.d1; li = c ? j : t.i1; d = c ? t.d1 : d; j = c ? t.i1 : j; t.d1 = lo; t.i1 = li;
+    c = d < t.d2 || (d == t.d2 && j < t.i2); lo = c ? d : t.d2; li = c ? j : t.i2; d = c ? t.d2 : d; j = c ? t.i2 : j; t.d2 = lo; t.i2 = li;
+    c = d < t.d3 || (d == t.d3 && j < t.i3); lo = c ? d : t.d3; li = c ? j : t.i3; d = c ? t.d3 : d; j = c ? t.i3 : j; t.d3 = lo; t.i3 = li;
+    c = d < t.d4 || (d == t.d4 && j < t.i4); t.d4 = c ? d : t.d4; t.i4 = c ? j : t.i4;
 }
 
 __device__ __forceinline__ void top5_insert(Top5& t, float d, int j) {
-    if (d < t.d4) top5_insert_nb(t, d, j);      // rare after the first few dozen candidates
+    if (d < t.d4) top5_insert_lex(t, d, j);     // rare after the first few dozen candidates; (d, index) order: a plain
+                                                // strict-< bubble lets a carried element overtake an equal one
 }
 
 // Exact brute-force scan of all K points (broadcast LDS reads) for the two points of this thread
@@ -114,8 +118,8 @@ __device__ __forceinline__ void list_top5_2(const f32x4* __restrict__ X, const u
         float db = fmaf(bz, bz, fmaf(by, by, bx * bx));
         da = cva ? da : INFINITY;
         db = cvb ? db : INFINITY;
-        top5_insert_nb(ta, da, cja);
-        top5_insert_nb(tb, db, cjb);
+        top5_insert_lex(ta, da, cja);
+        top5_insert_lex(tb, db, cjb);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -210,12 +214,15 @@ struct KnnPt {
 };
 
 // One target of the wave-cooperative ("transposed") list build: the lanes hold the K candidate points in registers
-// (16 each); one distance per candidate, hits are compacted with ballot / mbcnt into the target's list - no divergent
-// branches, exact counts.  tf / tb: squared front / back radii (wave-uniform).  Unused slots get the dummy index.
+// (16 each).  Every lane first collects its hits as two 16-bit masks (front ball / ring), the list positions come from
+// wave prefix sums of the hit counts, and each lane then stores its (typically 0-2) hits - ~250 instructions per
+// target instead of ~480 for a ballot / mbcnt compaction per candidate slice.  tf / tb: squared front / back radii
+// (wave-uniform).  Front hits beyond LIST_F go to the ring segment behind the ring's own hits, so the ring stays
+// complete when only the front overflows.  Unused slots get the dummy index.
 __device__ __forceinline__ void knn_build_one(const float (&cx)[16], const float (&cy)[16], const float (&cz)[16],
                                               const f32x4 xi, int i, int lane, float tf, float tb,
                                               uint16_t* __restrict__ lst, int& nf_out, int& nb_out) {
-    int nf = 0, nb = 0;                                                            // wave-uniform running counts
+    unsigned int hf = 0u, hb = 0u;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int j = lane + 64 * k;
@@ -223,21 +230,36 @@ __device__ __forceinline__ void knn_build_one(const float (&cx)[16], const float
         const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
         const bool in_b = d < tb && j != i;
         const bool in_f = d < tf && in_b;
-        const unsigned long long mf = __ballot(in_f);
-        const int pos_f = nf + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
-        const bool to_f = in_f && pos_f < LIST_F;
-        if (to_f) lst[pos_f] = (uint16_t)j;
-        nf += __popcll(mf);
-        const bool to_b = in_b && !to_f;                  // ring members + front hits that did not fit
-        const unsigned long long mb = __ballot(to_b);
-        const int pos_b = nb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
-        if (to_b && pos_b < LIST_B) lst[LIST_F + pos_b] = (uint16_t)j;
-        nb += __popcll(mb);
+        hf |= (in_f ? 1u : 0u) << k;
+        hb |= ((in_b && !in_f) ? 1u : 0u) << k;
     }
+    const int cf = __popc(hf), cb = __popc(hb);
+    int pf = cf, pb = cb;                                          // wave-inclusive prefix sums
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int tf_ = __shfl_up(pf, o), tb_ = __shfl_up(pb, o);
+        if (lane >= o) { pf += tf_; pb += tb_; }
+    }
+    const int nf = __shfl(pf, 63), nb = __shfl(pb, 63);
+    int at_f = pf - cf, at_b = pb - cb;
+    while (hf != 0u) {
+        const int k = __builtin_ctz(hf);
+        hf &= hf - 1u;
+        const int pos = at_f++;
+        const int slot = pos < LIST_F ? pos : LIST_F + nb + (pos - LIST_F);       // overflowing front hits: behind the ring's
+        if (slot < LIST_M) lst[slot] = (uint16_t)(lane + 64 * k);
+    }
+    while (hb != 0u) {
+        const int k = __builtin_ctz(hb);
+        hb &= hb - 1u;
+        const int pos = at_b++;
+        if (pos < LIST_B) lst[LIST_F + pos] = (uint16_t)(lane + 64 * k);
+    }
+    const int nb_all = nb + max(nf - LIST_F, 0);                                   // ring members + front hits that did not fit
     // unused slots point at the dummy X[MAXK] (the key evaluation does not look at counts)
-    if (lane < LIST_M && lane >= (lane < LIST_F ? nf : LIST_F + nb)) lst[lane] = (uint16_t)MAXK;
+    if (lane < LIST_M && lane >= (lane < LIST_F ? nf : LIST_F + nb_all)) lst[lane] = (uint16_t)MAXK;
     nf_out = nf;
-    nb_out = nb;
+    nb_out = nb_all;
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l) {
