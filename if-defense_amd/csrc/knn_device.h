@@ -375,6 +375,57 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
     }
 }
 
+// The two owned points together (optimiser): one instruction stream with the two independent chains interleaved -
+// two rep_point calls under separate `if (p < K)` branches cannot overlap their LDS / sqrt / exp / divide latencies.
+__device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, long long* __restrict__ F, int K, int pa, int pb,
+                                           const Top5& ta, const Top5& tb, const RepConst rc, float& loss_a,
+                                           float& loss_b, long long (&gca)[3], long long (&gcb)[3]) {
+    const bool va = pa < K, vb = pb < K;
+    const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
+    const int ia[5] = {ta.i0, ta.i1, ta.i2, ta.i3, ta.i4}, ib[5] = {tb.i0, tb.i1, tb.i2, tb.i3, tb.i4};
+    float la = 0.f, lb = 0.f;
+    gca[0] = gca[1] = gca[2] = 0;
+    gcb[0] = gcb[1] = gcb[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int ja = va ? ia[k] : 0, jb = vb ? ib[k] : 0;
+        const f32x4 qa = X[ja], qb = X[jb];
+        long long f[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 xi = s ? xb : xa, xj = s ? qb : qa;
+            const float ex = xj.x - xi.x, ey = xj.y - xi.y, ez = xj.z - xi.z;
+            const float d2raw = ex * ex + ey * ey + ez * ez;
+            const float d2 = fmaxf(d2raw, rc.eps);
+            const float d = sqrtf(d2);
+            const float q = d / rc.h;
+            const float w = expf(-(q * q));
+            (s ? lb : la) += (rc.radius - d) * w;
+            const float dd = -w - (rc.radius - d) * w * (2.f * q / rc.h);
+            const float coef = d2raw > rc.eps ? dd / d : 0.f;
+            f[s][0] = __float2ll_rn(coef * ex * FIX_SCALE);
+            f[s][1] = __float2ll_rn(coef * ey * FIX_SCALE);
+            f[s][2] = __float2ll_rn(coef * ez * FIX_SCALE);
+        }
+        if (va) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                gca[a] -= f[0][a];
+                atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * ja + a), (unsigned long long)f[0][a]);
+            }
+        }
+        if (vb) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                gcb[a] -= f[1][a];
+                atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * jb + a), (unsigned long long)f[1][a]);
+            }
+        }
+    }
+    loss_a = la;
+    loss_b = lb;
+}
+
 // ---------------------------------------------------------------------------------------------
 // block helpers
 // ---------------------------------------------------------------------------------------------
@@ -606,8 +657,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
         if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
         PROF_ACC(pc_eval);
     }
-    if (pa < K) rep_point(X, F, pa, ta, rc, rep_loss_a, gca, true);
-    if (pb < K) rep_point(X, F, pb, tb, rc, rep_loss_b, gcb, true);
+    rep_point2(X, F, K, pa, pb, ta, tb, rc, rep_loss_a, rep_loss_b, gca, gcb);
     PROF_ACC(pc_rep);
 }
 
