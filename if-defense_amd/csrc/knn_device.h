@@ -62,16 +62,17 @@ __device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Certified neighbour lists: exact 5-NN at O(LIST_M) per point per step.
+// Certified neighbour lists: exact 5-NN at O(LIST_M) per point per step (DESIGN.md section 5).
 //
-//   build (rare, all waves of the cloud in the same step):  for each point i store every j with
-//       |x_j - x_i| < rho_i, rho_i^2 = alpha2_i * (an upper bound of i's squared 5-NN distance); alpha2_i
-//       adapts so that the ball holds <= LIST_M points.  x0_i = x_i at build time.
-//   step:  the 5 nearest list members are the true 5-NN iff  r5 < rho_i - |x_i - x0_i| - Dmax, with
-//       Dmax = max_j |x_j - x0_j|  (a point outside the list was >= rho_i away at build time).
-//       soft margin violated -> request a synchronous rebuild for the NEXT step (nobody stalls alone);
+//   build:  for each point i store every j with |x_j - x_i| < rho_i, rho_i^2 = alpha2_i * (an upper bound of i's
+//       squared 5-NN distance) - a LIST_F-entry front ball and a LIST_B-entry ring; the alpha2 adapt so that the
+//       counts stay in range.  x0_i = x_i at build time.  Whole-cloud rebuilds (every wave, same step) start an
+//       epoch; short-lived ("fragile") certificates are refreshed individually by their own wave.
+//   step:  the 5 nearest list members are the true 5-NN iff  r5 < rho_i - |x_i - x0_i| - (D(now) + D(t_i)), with
+//       D(t) = max_j (|x_j(t) - x0_j| + D(t_j))  bounding every point's displacement since the epoch start (a point
+//       outside the list was >= rho_i away at build time).  Soft margin violated -> new lists for the NEXT step;
 //       certificate violated -> this wave runs the exact brute-force scan for this step.
-//   Either way every step uses the exact 5-NN set; ties follow ascending j like the scan.
+//   Either way every step uses the exact 5-NN set = the five smallest (distance, index) pairs, like the scan.
 // ---------------------------------------------------------------------------------------------
 constexpr int LIST_F = 16;               // "front": every point within rho_f at build time (evaluated every step)
 constexpr int LIST_B = 32;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)

@@ -1,20 +1,19 @@
 // ConvONet-Opt hot loop for MI355X (gfx950): one workgroup (8 waves, 2 per SIMD, 256 VGPRs each) owns one
-// cloud for all Adam steps; one thread owns two points for the kNN / Adam phases, one wave owns a 16-point
-// tile at a time for the decoder phase.
+// cloud for all Adam steps; one thread owns two points for the kNN / Adam phases, one wave owns a 32-point
+// tile (two software-pipelined 16-point sub-tiles) at a time for the decoder phase.
 //
 //   per step (reference: ConvONet/opt_defense.py:210-228)
-//     phase A  decoder forward + input-gradient on 16-point tiles:
-//              bilinear gather of the 3 channel-last planes (decoder.py:50-57), the 5-block ResNet MLP on
-//              v_mfma_f32_16x16x4_f32 (decoder.py:83-93, layers.py:39-48), BCE-to-threshold derivative
-//              (opt_defense.py:213-216), transposed MLP, dc/du from the taps still held in registers.
-//              All 24 tap loads of a tile are issued as one batch (one memory round trip per tile).
-//     phase B  exact 5-NN from certified neighbour lists (defense/pn_utils.py:64-83) + repulsion loss
-//              gradient (defense/repulsion_loss.py:43-54); neighbour terms are scattered with 64-bit
-//              fixed-point LDS atomics => order independent, bit reproducible.
-//     phase C  fused Adam update (torch.optim.Adam single-tensor form), moments in registers.
-//   Half of the waves run A then B, the other half B then A, so every SIMD always has MFMA work queued
-//   next to the VALU-only kNN work.  Nothing but the plane taps (and the L2-resident neighbour lists) is
-//   read from global memory inside the loop.
+//     kNN      exact 5-NN from certified neighbour lists (defense/pn_utils.py:64-83; knn_device.h) + repulsion
+//              loss gradient (defense/repulsion_loss.py:43-54); neighbour AND centre terms are accumulated in 64-bit
+//              fixed point (LDS atomics) => order independent, bit reproducible.  All waves run this phase first,
+//              together: a VALU-only wave next to an MFMA wave on a SIMD gains nothing (no MFMA/VALU overlap on
+//              gfx950) and is starved.
+//     tiles    decoder forward + input-gradient, tiles pulled from an LDS counter: bilinear gather of the 3
+//              channel-last planes (decoder.py:50-57; all three planes in flight - the taps come from HBM / Infinity
+//              Cache), the 5-block ResNet MLP on v_mfma_f32_16x16x4_f32 (decoder.py:83-93, layers.py:39-48),
+//              BCE-to-threshold derivative (opt_defense.py:213-216), transposed MLP, dc/du from re-gathered taps.
+//     Adam     fused update (torch.optim.Adam single-tensor form), moments in registers.
+//   Nothing but the plane taps (and the L2-resident neighbour lists) is read from global memory inside the loop.
 //
 // MFMA operand mapping (16x16x4, f32): M = output channel, N = point of the tile, K = input channel.
 //   lane l = (n = l & 15, q = l >> 4).  A-operand: A[m = n][k = q];  B-operand: B[k = q][n];  C/D: lane
