@@ -784,3 +784,19 @@ def test_onet_mesh_samples_match_oracle_distribution(onet, og):
     cd_self, cd_hip = _chamfer(a, b), 0.5 * (_chamfer(hip, a) + _chamfer(hip, b))
     print("ONet-Mesh samples: Chamfer HIP<->oracle %.4f, oracle seed<->seed %.4f" % (cd_hip, cd_self))
     assert cd_hip < 1.15 * cd_self
+
+
+def test_lists_equal_scan_on_mixed_inputs(restorer):
+    """Regression net for the neighbour lists (exact ties, refreshes, ragged K): a slice of scripts/fuzz_lists_vs_scan.py."""
+    import bench
+    rng = np.random.default_rng(5)
+    for it, make in enumerate((lambda c: c, bench.knn_attack_like, lambda c: bench.subsample_like(c, 256))):
+        clouds = make(bench.synth_clouds(14, seed=300 + it))
+        x = torch.from_numpy(clouds).cuda()
+        prep = restorer.prepare(x, restorer.sor(x), seed=it)
+        planes = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        for K, steps in ((1024, 200), (int(rng.integers(6, 600)), 120)):
+            init = prep["init"][:, :K].contiguous()
+            a = restorer.optimize_points(init, planes, rep_weight=500.0, steps=steps, normalize=False)
+            b = restorer.optimize_points(init, planes, rep_weight=500.0, steps=steps, normalize=False, knn_scan_every_step=True)
+            assert torch.equal(a, b), (it, K, steps)
