@@ -335,6 +335,76 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
     }
 }
 
+// Exact 5-NN of a FEW points of this wave whose certificate failed (crowded balls, late failures): the wave's
+// lanes hold the K candidates (16 each), per target five rounds of a (distance, index)-lexicographic minimum -
+// ~500 instructions per target instead of a ~20 k-instruction scan by every lane of the wave.  Falls back to that
+// scan when many lanes failed.
+__device__ __forceinline__ void knn_resolve_failures(const f32x4* __restrict__ X, int K, int wave, int lane, int pa, int pb,
+                                                     bool fail_a, bool fail_b, Top5& ta, Top5& tb) {
+    const unsigned long long ma = __ballot(fail_a), mb = __ballot(fail_b);
+    if (__popcll(ma) + __popcll(mb) > 24) {
+        knn_scan2(X, K, pa, pb, ta, tb);
+        return;
+    }
+    float cx[16], cy[16], cz[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = lane + 64 * k;
+        const f32x4 p = X[min(j, K - 1)];
+        const bool v = j < K;
+        cx[k] = v ? p.x : 1e18f; cy[k] = v ? p.y : 1e18f; cz[k] = v ? p.z : 1e18f;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        Top5& t = half ? tb : ta;
+        unsigned long long mask = half ? mb : ma;
+#pragma unroll 1
+        while (mask != 0ull) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int i = (half ? OPT_THREADS : 0) + wave * 64 + l;
+            const f32x4 xi = X[i];
+            float d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float ex = cx[k] - xi.x, ey = cy[k] - xi.y, ez = cz[k] - xi.z;
+                d[k] = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+                if (lane + 64 * k == i || lane + 64 * k >= K) d[k] = INFINITY;
+            }
+            float rd[5];
+            int rj[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                float bd = d[0];
+                int bk = 0;
+#pragma unroll
+                for (int k = 1; k < 16; ++k)
+                    if (d[k] < bd) { bd = d[k]; bk = k; }            // ascending k = ascending index: ties keep the smaller
+                int bj = lane + 64 * bk;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float od = __shfl_xor(bd, o);
+                    const int oj = __shfl_xor(bj, o);
+                    const bool take = od < bd || (od == bd && oj < bj);
+                    bd = take ? od : bd;
+                    bj = take ? oj : bj;
+                }
+                rd[r] = bd;
+                rj[r] = bj;
+                if ((bj & 63) == lane) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (k == (bj >> 6)) d[k] = INFINITY;
+                }
+            }
+            if (lane == l) {
+                t.d0 = rd[0]; t.d1 = rd[1]; t.d2 = rd[2]; t.d3 = rd[3]; t.d4 = rd[4];
+                t.i0 = rj[0]; t.i1 = rj[1]; t.i2 = rj[2]; t.i3 = rj[3]; t.i4 = rj[4];
+            }
+        }
+    }
+}
+
 struct RepConst {
     float radius, h, eps;
 };
@@ -599,30 +669,27 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
             // every point outside a ball of build radius rho is now farther than rho - (spent budget)
             const bool ok1 = (pa >= K || r5a < (ka.rho_f - hs_a) * 0.99999f - 1e-7f) &&
                              (pb >= K || r5b < (kb.rho_f - hs_b) * 0.99999f - 1e-7f);
-            bool scanned = false;
+            bool fail_a = false, fail_b = false;      // hard certificate failures (only possible once the ring was needed)
             if (!__all(ok1)) {
                 ++cn.n_tier2;
                 list_keys6_2<LIST_F / 8, LIST_M / 8>(X, wa, wb, ia, ib, qa, qb);
                 r5a = sqrtf(key_d_upper(qa.k4));
                 r5b = sqrtf(key_d_upper(qb.k4));
-                const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f)) &&
-                                  (pb >= K || (kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f));
-                if (!__all(hard)) {      // certificate failed: exact scan for this wave, this step
-                    ++cn.n_brute;
-                    knn_scan2(X, K, pa, pb, ta, tb);
-                    scanned = true;
-                }
-                // will it still hold next step?  (crowded balls, cnt_b < 0, are served by the scan anyway)
+                fail_a = pa < K && !(ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f);
+                fail_b = pb < K && !(kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f);
+                // will it still hold next step?  (crowded balls, cnt_b < 0, are served by the exact query anyway)
                 soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
                 soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
             }
-            if (!scanned) {
-                const bool amb = (pa < K && keys6_ambiguous(qa)) || (pb < K && keys6_ambiguous(qb));
-                if (__any(amb)) {
-                    exact = true;
-                } else {
-                    keys6_to_top5(qa, ta);
-                    keys6_to_top5(qb, tb);
+            const bool amb = (pa < K && !fail_a && keys6_ambiguous(qa)) || (pb < K && !fail_b && keys6_ambiguous(qb));
+            if (__any(amb)) {
+                exact = true;
+            } else {
+                keys6_to_top5(qa, ta);
+                keys6_to_top5(qb, tb);
+                if (__any(fail_a || fail_b)) {       // certificate failed: exact query for those points, this step
+                    ++cn.n_brute;
+                    knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
             }
         }
@@ -638,11 +705,11 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
             if (!__all(ok1)) {
                 list_top5_2<LIST_F, LIST_M>(X, La, Lb, LIST_F + ka.cnt_b, LIST_F + kb.cnt_b, ia, ib, ta, tb);
                 const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
-                const bool hard = (pa >= K || (ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f)) &&
-                                  (pb >= K || (kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f));
-                if (!__all(hard)) {
+                const bool fail_a = pa < K && !(ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f);
+                const bool fail_b = pb < K && !(kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f);
+                if (__any(fail_a || fail_b)) {
                     ++cn.n_brute;
-                    knn_scan2(X, K, pa, pb, ta, tb);
+                    knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
                 soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
                 soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
