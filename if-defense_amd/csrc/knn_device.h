@@ -687,7 +687,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
             } else {
                 keys6_to_top5(qa, ta);
                 keys6_to_top5(qb, tb);
-                if (__any(fail_a || fail_b)) {       // certificate failed: exact query for those points, this step
+                if (__builtin_expect(__any(fail_a || fail_b), 0)) {       // certificate failed: exact query for those points, this step
                     ++cn.n_brute;
                     knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
@@ -707,7 +707,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                 const float r5a = sqrtf(ta.d4), r5b = sqrtf(tb.d4);
                 const bool fail_a = pa < K && !(ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f);
                 const bool fail_b = pb < K && !(kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f);
-                if (__any(fail_a || fail_b)) {
+                if (__builtin_expect(__any(fail_a || fail_b), 0)) {
                     ++cn.n_brute;
                     knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
