@@ -50,8 +50,16 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
+STAMP = os.path.join(CSRC, ".build_flags")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.{hip,cpp} into libifd.so.  The flag set of the last build is kept in csrc/.build_flags: a
+    library built with different flags (e.g. a diagnostic IFD_EXTRA_FLAGS="-DIFD_PROF" build) is always rebuilt."""
     srcs = sources()
+    flags = " ".join(f for f in FLAGS if not f.startswith("-I"))      # location-independent: the tree travels to the GPU box
+    if not os.path.exists(STAMP) or open(STAMP).read() != flags:
+        force = True
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if force or _stale(LIB, objs):
@@ -59,6 +67,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(STAMP, "w") as f:
+        f.write(flags)
     if verbose:
         print("built", LIB)
     return LIB
