@@ -26,24 +26,28 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int, int]:
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns
-    (rank, world, local_rank); a no-op single-process fallback when WORLD_SIZE is unset or 1."""
+    (rank, world, local_rank).  A plain `python x.py` run (WORLD_SIZE unset) stays single-process with no process
+    group; under torchrun the group is created even for one rank, so that `--nproc-per-node 1` on a one-GPU box
+    exercises the same RCCL calls (communicator, barrier, all-gather) as the N > 1 runs."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)      # bind the RCCL communicator (and barrier()) to this rank's GPU
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
 def gather_shards(local: torch.Tensor, n_total: int, per: int) -> torch.Tensor:
     """All-gather equal-length (padded) shards and trim: every rank returns the full [n_total, ...] array."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local[:n_total]
+    world = dist.get_world_size()
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -55,7 +59,7 @@ def defend_sharded(defend: Callable[[np.ndarray, int, int], torch.Tensor], pc: n
     """Run `defend(shard, cloud_index_base, total)` on this rank's contiguous shard of `pc` and all-gather.
 
     Because random draws are keyed by the global cloud index and the 1/B loss factor by the reference batch a
-    cloud belongs to, the gathered array is bit-identical to a single-process run (tests/test_dist_cpu.py,
+    cloud belongs to, the gathered array is bit-identical to a single-process run (tests/test_host_cpu.py,
     tests/test_gpu_parity.py::test_defend_point_cloud_end_to_end_and_sharding).
     """
     world = dist.get_world_size() if dist.is_initialized() else 1

@@ -800,3 +800,72 @@ def test_lists_equal_scan_on_mixed_inputs(restorer):
             a = restorer.optimize_points(init, planes, rep_weight=500.0, steps=steps, normalize=False)
             b = restorer.optimize_points(init, planes, rep_weight=500.0, steps=steps, normalize=False, knn_scan_every_step=True)
             assert torch.equal(a, b), (it, K, steps)
+
+
+_RCCL_SCRIPT = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import ifdefense_amd as I
+from ifdefense_amd import dist as D
+
+rank, world, local = D.init_from_env()
+assert dist.is_initialized() and dist.get_backend() == "nccl", "torchrun launch must create the RCCL group"
+dev = torch.device("cuda", local)
+r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device=dev)
+pc = np.load(sys.argv[2])
+args = I.DefenseArgs(iterations=10, seed=3)
+
+def defend(shard, base, total):
+    return I.defend_point_cloud(r, torch.from_numpy(shard).to(dev), args, cloud_index_base=base, total_clouds=total,
+                                return_device=True)
+
+out = D.defend_sharded(defend, pc)
+t = torch.tensor([float(rank + 1)], device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == float(world)
+if rank == 0:
+    np.save(sys.argv[3], out.cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_path_under_torchrun(tmp_path):
+    """The N > 1 launch line of the bench contract with one rank: `python -m torch.distributed.run --nproc-per-node 1`
+    creates the RCCL communicator on the GPU, and sharding + ncclAllGather + barrier + all-reduce run for real.  The
+    gathered array is bit-identical to the in-process result; bench.py prints its one JSON line under the same launch."""
+    import json, os, socket, subprocess, sys
+    import ifdefense_amd as I
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(11)
+    v = rng.normal(size=(5, 1024, 3)).astype(np.float32)
+    pc = (v / np.linalg.norm(v, axis=-1, keepdims=True) * rng.uniform(0.3, 1.0, size=(5, 1024, 1))).astype(np.float32)
+    np.save(tmp_path / "pc.npy", pc)
+    (tmp_path / "rccl_run.py").write_text(_RCCL_SCRIPT)
+
+    def launch(script_args):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args,
+                              capture_output=True, text=True, cwd=root, timeout=900, env=env)
+
+    r = launch([str(tmp_path / "rccl_run.py"), root, str(tmp_path / "pc.npy"), str(tmp_path / "out.npy")])
+    assert r.returncode == 0, r.stdout + r.stderr
+    args = I.DefenseArgs(iterations=10, seed=3)
+    r0 = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device="cuda:0")
+    want = I.defend_point_cloud(r0, torch.from_numpy(pc).cuda(), args, cloud_index_base=0, total_clouds=5,
+                                return_device=True).cpu().numpy()
+    r0.close()
+    assert np.array_equal(np.load(tmp_path / "out.npy"), want)
+
+    r = launch(["bench.py", "--gpus", "1", "--clouds", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "shard1+allgather"
+    assert 0.05 < line["roofline"]["frac"] < 1.0
