@@ -869,3 +869,18 @@ def test_rccl_path_under_torchrun(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "shard1+allgather"
     assert 0.05 < line["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.parametrize("k", [6, 7, 16, 17, 33, 48, 49, 100, 333, 777, 1023])
+def test_optimise_point_count_sweep(restorer, golden, planes2, oracle_weights, k):
+    """Every boundary of the kernel's blocking: K = 6 is the smallest cloud with five neighbours, 16 / 32 the decoder's
+    sub-tile / tile, 48 the neighbour-list length, 1023 one short of the maximum.  Six free-running steps against the
+    oracle (tolerance of P2: 1e-3 after 10 steps; here 1e-4 after 6), with a teacher-forced single step at 1e-6."""
+    from oracle import convonet_oracle as O
+    init = torch.from_numpy(golden["init_points"][:2, :k]).clone()
+    one = O.optimize_points(oracle_weights, init, planes2, rep_weight=500.0, iterations=0, normalize=False)
+    got1 = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=0, normalize=False)
+    assert np.abs(got1.cpu().numpy() - one.numpy()).max() <= 1e-6
+    ref = O.optimize_points(oracle_weights, init, planes2, rep_weight=500.0, iterations=5, normalize=True)
+    got = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=5, normalize=True)
+    assert np.linalg.norm(got.cpu().numpy() - ref.numpy(), axis=-1).max() < 1e-4
