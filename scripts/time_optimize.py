@@ -38,5 +38,5 @@ for _ in range(a.reps):
              cps * 2 * 15488 * 2 * 1024 * a.steps / 1e12, cps * 2 * 15488 * 2 * 1024 * a.steps / 157.3e12 * 100))
 assert torch.isfinite(out).all()
 c = r.counters()
-print('effective shader clock while cloud 0 ran: %.2f GHz (cycles %d over the last launch of %.1f ms; valid for <= 256 clouds)' % (c['cloud0_shader_cycles'] / (ms * 1e-3) / 1e9, c['cloud0_shader_cycles'], ms))
+print('effective shader clock while cloud 0 ran: %.2f GHz (cycles %d over the last launch of %.1f ms; valid for <= 256 clouds) -> %.1f k shader cycles per step' % (c['cloud0_shader_cycles'] / (ms * 1e-3) / 1e9, c['cloud0_shader_cycles'], ms, c['cloud0_shader_cycles'] / a.steps / 1e3))
 print('counters', c, '-> rebuilds per wave per run: %.1f' % (c['knn_rebuilds'] / (B * 8)))
