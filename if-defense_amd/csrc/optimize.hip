@@ -345,16 +345,21 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 //   * 4 independent accumulator chains per layer (2 sub-tiles x 2 M-tiles): no dependent-MFMA stalls, and the
 //     VALU epilogue of one sub-tile (bias, ReLU, mask) overlaps the other sub-tile's MFMAs;
 //   * every A operand (weight) is fetched from LDS once and feeds both sub-tiles: half the LDS reads per MFMA;
-//   * ReLU masks are packed 8 bits per layer and made opaque (asm) so the compiler keeps them as 1 VGPR each.
+//   * ReLU masks are packed 8 bits per layer (one v_alignbit per value going in, v_bfe_i32 + v_bfi per value coming
+//     out) and made opaque (asm) so the compiler keeps them as 1 VGPR each.
 // The taps are gathered one plane at a time and re-gathered for the backward pass (L1/L2 hits): holding them
 // for two sub-tiles would need 192 VGPRs.
 // ---------------------------------------------------------------------------------------------
+// Bit (7 - r) of the result = "value r is NOT positive": the sign of (bits(relu(v)) - 1) shifted in with one v_alignbit
+// per value (relu(v) = +0 -> 0xffffffff, any positive float -> a positive integer).  Exact at +-0 like v > 0.
 __device__ __forceinline__ uint32_t mask_pos_packed(const f32x8& v) {
-    uint32_t b[8];
+    uint32_t m = 0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) b[r] = v[r] > 0.f ? (1u << r) : 0u;
-    uint32_t m = ((b[0] | b[1]) | (b[2] | b[3])) | ((b[4] | b[5]) | (b[6] | b[7]));
-    asm volatile("" : "+v"(m));      // keep it a bit-mask: otherwise hipcc re-expands it into 8 float selectors
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t t = (uint32_t)max(__float_as_int(v[r]), 0) - 1u;
+        m = __builtin_amdgcn_alignbit(m, t, 31);
+    }
+    asm volatile("" : "+v"(m));
     return m;
 }
 
@@ -440,7 +445,12 @@ __device__ __forceinline__ Acc2 acc_zero() {
 __device__ __forceinline__ f32x8 masked(const Acc2& z, uint32_t m) {
     f32x8 v = flat(z);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = ((m >> r) & 1u) ? v[r] : 0.f;
+    for (int r = 0; r < 8; ++r) {
+        uint32_t dead, o;                                         // v_bfe_i32: 0 / -1 ; v_bfi: v & ~dead
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(dead) : "v"(m), "n"(7 - r));
+        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(o) : "v"(dead), "v"(__float_as_uint(v[r])));
+        v[r] = __uint_as_float(o);
+    }
     return v;
 }
 
