@@ -27,6 +27,7 @@
 #include "knn_device.h"
 
 namespace ifd {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
@@ -430,12 +431,26 @@ __device__ __forceinline__ void region_end() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// four v_pk_add_f32 instead of eight v_add_f32 (the accumulator quads are register pairs)
+__device__ __forceinline__ f32x4 add4_pk(const f32x4& a, const f32x4& b) {
+    const f32x2 lo = f32x2{a.x, a.y} + f32x2{b.x, b.y};
+    const f32x2 hi = f32x2{a.z, a.w} + f32x2{b.z, b.w};
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ Acc2 acc_add(const Acc2& a, const Acc2& b) {
     Acc2 r;
-    r.t[0] = a.t[0] + b.t[0];
-    r.t[1] = a.t[1] + b.t[1];
+    r.t[0] = add4_pk(a.t[0], b.t[0]);
+    r.t[1] = add4_pk(a.t[1], b.t[1]);
     return r;
 }
+__device__ __forceinline__ void add8_pk(f32x8& d, const f32x8& t) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const f32x2 v = f32x2{d[2 * h], d[2 * h + 1]} + f32x2{t[2 * h], t[2 * h + 1]};
+        d[2 * h] = v.x; d[2 * h + 1] = v.y;
+    }
+}
+
 __device__ __forceinline__ Acc2 acc_zero() {
     Acc2 r;
     r.t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -641,15 +656,13 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         mfma16(A0, dh1, y1);
         {
             const f32x8 t = masked(y0, mask_a[0][i]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) dn[0][r] += t[r];                      // delta a_i
+            add8_pk(dn[0], t);                                                 // delta a_i
         }
         region_end<1, 1>();
         mfma16(Ac, dn[0], dcc[0]);                                             // R5: dc += fc_c^T da (sub-tile 0)
         {
             const f32x8 t = masked(y1, mask_a[1][i]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) dn[1][r] += t[r];
+            add8_pk(dn[1], t);
         }
         region_end<1, 0>();
         if (i > 0) A = load_wfrag<true>(Wl - W_LAYER, lo);                    // R6: prefetch fc_1[i-1]^T
@@ -672,20 +685,24 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         }
     // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
     f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
+    // packed along the channels (even / odd partial sums, added at the end): register pairs as loaded, no shuffling
     auto sample_bwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const SubGeo& gg = geo[t];
-            float dnw = 0.f, dne = 0.f, dsw = 0.f, dse = 0.f;
+            f32x2 pnw = {0.f, 0.f}, pne = {0.f, 0.f}, psw = {0.f, 0.f}, pse = {0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = dcf[t][4 * mt + j];
-                    dnw = fmaf(tap[t][0][mt][j], d, dnw); dne = fmaf(tap[t][1][mt][j], d, dne);
-                    dsw = fmaf(tap[t][2][mt][j], d, dsw); dse = fmaf(tap[t][3][mt][j], d, dse);
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 d = {dcf[t][4 * mt + 2 * h], dcf[t][4 * mt + 2 * h + 1]};
+                    pnw = __builtin_elementwise_fma(f32x2{tap[t][0][mt][2 * h], tap[t][0][mt][2 * h + 1]}, d, pnw);
+                    pne = __builtin_elementwise_fma(f32x2{tap[t][1][mt][2 * h], tap[t][1][mt][2 * h + 1]}, d, pne);
+                    psw = __builtin_elementwise_fma(f32x2{tap[t][2][mt][2 * h], tap[t][2][mt][2 * h + 1]}, d, psw);
+                    pse = __builtin_elementwise_fma(f32x2{tap[t][3][mt][2 * h], tap[t][3][mt][2 * h + 1]}, d, pse);
                 }
+            const float dnw = pnw.x + pnw.y, dne = pne.x + pne.y, dsw = psw.x + psw.y, dse = pse.x + pse.y;
             const float gix = (dne - dnw) * gg.w0[a1] + (dse - dsw) * gg.w1[a1];
             const float giy = (dsw - dnw) * gg.w0[a0] + (dse - dne) * gg.w1[a0];
             const float sc = (0.5f * (float)(RES - 1)) * 2.f;
