@@ -507,35 +507,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
             }
         }
     };
-#ifdef IFD_X_PKF
-    // two channels per instruction: the taps of a dwordx4 load and the channels of c are register pairs, the bilinear
-    // weight is broadcast (v_pk_mul_f32 / v_pk_fma_f32); per channel the same mul, fma, fma, fma, add as the scalar form
-    auto sample_fwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
-        const int a0 = AX0[P], a1 = AX1[P];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const SubGeo& g = geo[t];
-            const float wnw = g.w0[a0] * g.w0[a1], wne = g.w1[a0] * g.w0[a1], wsw = g.w0[a0] * g.w1[a1],
-                        wse = g.w1[a0] * g.w1[a1];
-            const f32x2 vnw = {wnw, wnw}, vne = {wne, wne}, vsw = {wsw, wsw}, vse = {wse, wse};
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x2 t0 = {tap[t][0][mt][2 * h], tap[t][0][mt][2 * h + 1]};
-                    const f32x2 t1 = {tap[t][1][mt][2 * h], tap[t][1][mt][2 * h + 1]};
-                    const f32x2 t2 = {tap[t][2][mt][2 * h], tap[t][2][mt][2 * h + 1]};
-                    const f32x2 t3 = {tap[t][3][mt][2 * h], tap[t][3][mt][2 * h + 1]};
-                    f32x2 sv = t0 * vnw;
-                    sv = __builtin_elementwise_fma(t1, vne, sv);
-                    sv = __builtin_elementwise_fma(t2, vsw, sv);
-                    sv = __builtin_elementwise_fma(t3, vse, sv);
-                    c[t][4 * mt + 2 * h] += sv.x;
-                    c[t][4 * mt + 2 * h + 1] += sv.y;
-                }
-        }
-    };
-#else
     auto sample_fwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -555,7 +526,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
                 }
         }
     };
-#endif
     {
         f32x4 tap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
         load_taps(0, tap0, false);
