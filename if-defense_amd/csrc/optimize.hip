@@ -686,6 +686,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
     // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
     f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
     // packed along the channels (even / odd partial sums, added at the end): register pairs as loaded, no shuffling
+    // d pix / d x = (RES - 1) / 2 * 2 / sdiv as one constant (the reference multiplies and divides in sequence; the
+    // difference is a rounding in the last place of a gradient term)
+    const float ksc = ((0.5f * (float)(RES - 1)) * 2.f) / dc.sdiv;
     auto sample_bwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -711,9 +714,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
             float gix, giy;
             asm("v_add_f32 %0, %1, %2" : "=v"(gix) : "v"(pgx.x), "v"(pgx.y));
             asm("v_add_f32 %0, %1, %2" : "=v"(giy) : "v"(pgy.x), "v"(pgy.y));
-            const float sc = (0.5f * (float)(RES - 1)) * 2.f;
-            g[t][a0] += gg.live[a0] * ((gix * sc) / dc.sdiv);
-            g[t][a1] += gg.live[a1] * ((giy * sc) / dc.sdiv);
+            g[t][a0] = fmaf(gg.live[a0] * ksc, gix, g[t][a0]);
+            g[t][a1] = fmaf(gg.live[a1] * ksc, giy, g[t][a1]);
         }
     };
     {

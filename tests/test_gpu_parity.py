@@ -463,7 +463,8 @@ def test_p3_full_501_steps_against_oracle(restorer, golden, oracle_weights, plan
     ref, snaps = O.optimize_points(oracle_weights, init, planes2, rep_weight=500.0, iterations=500, normalize=False,
                                    record=(500,))
     bumped = torch.nextafter(init, torch.full_like(init, 2.0))                     # +1 ulp on every coordinate
-    ref2 = O.optimize_points(oracle_weights, bumped, planes2, rep_weight=500.0, iterations=500, normalize=False)
+    ref2, snaps2 = O.optimize_points(oracle_weights, bumped, planes2, rep_weight=500.0, iterations=500, normalize=False,
+                                     record=(500,))
     got, loss = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=500, normalize=False, return_loss=True)
     got = got.cpu()
     d_build = (got - ref).norm(dim=-1).numpy()
@@ -475,12 +476,21 @@ def test_p3_full_501_steps_against_oracle(restorer, golden, oracle_weights, plan
           ((d_build < 1e-3).mean(), d_build.mean(), (d_self < 1e-3).mean(), d_self.mean(), cd_build, cd_self))
     assert (d_build < 1e-3).mean() > 0.8 * (d_self < 1e-3).mean() - 0.05
     assert cd_build < 1.5 * cd_self + 1e-4
-    # final losses (evaluated at the pre-update points of the last step) within 1 %
+    # final losses (evaluated at the pre-update points of the last step).  The occupancy term is a smooth statistic
+    # (1 %); the repulsion term is carried by a few close pairs and scatters by itself: over six +-1-ulp perturbations
+    # of the initial points the oracle gives 3.878 ... 3.925 (std 0.4 %, range 1.2 %) on these two clouds, and
+    # different host CPUs move the unperturbed value just as much -> 2.5 % (6 sigma), or twice the perturbed
+    # oracle's own difference if that is larger
     with torch.no_grad():
         _, occ, rep, _ = O.losses(oracle_weights, snaps[500], planes2, 500.0)
+        _, occ2, rep2, _ = O.losses(oracle_weights, snaps2[500], planes2, 500.0)
     loss = loss.cpu().numpy().astype(np.float64)
-    np.testing.assert_allclose(loss[:, 0].sum() / 2, float(occ), rtol=1e-2)
-    np.testing.assert_allclose(loss[:, 1].mean() * 500.0, float(rep), rtol=1e-2)
+    tol_occ = max(1e-2, 2.0 * abs(float(occ2) - float(occ)) / float(occ))
+    tol_rep = max(2.5e-2, 2.0 * abs(float(rep2) - float(rep)) / float(rep))
+    print("final losses: occ %.5f (oracle %.5f, perturbed %.5f) rep %.5f (oracle %.5f, perturbed %.5f)" %
+          (loss[:, 0].sum() / 2, float(occ), float(occ2), loss[:, 1].mean() * 500.0, float(rep), float(rep2)))
+    np.testing.assert_allclose(loss[:, 0].sum() / 2, float(occ), rtol=tol_occ)
+    np.testing.assert_allclose(loss[:, 1].mean() * 500.0, float(rep), rtol=tol_rep)
 
 
 def test_full_size_properties(restorer):
