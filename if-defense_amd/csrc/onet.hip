@@ -242,9 +242,15 @@ __device__ __forceinline__ void layer_mfma(const float* __restrict__ img, float*
     }
 }
 
-// u = relu(a x + b) for the 64 channels this lane holds; returns the ReLU bit-mask (bit s <-> in[s])
-__device__ __forceinline__ unsigned long long cbn_relu(const float* __restrict__ ab, int q, const f32x4 (&x)[16], float (&u)[64]) {
-    unsigned long long m = 0ull;
+// ReLU masks of the 64 channels a lane holds: bit (31 - k % 32) of word k / 32 = "value k is NOT positive".  One
+// v_alignbit per value going in (the sign of bits(relu(v)) - 1), v_bfe_i32 + v_bfi per value coming out - every
+// vector instruction costs SIMD time next to the MFMAs.
+struct Mask64 {
+    unsigned int w[2];
+};
+// u = relu(a x + b) for the 64 channels this lane holds; returns the ReLU mask
+__device__ __forceinline__ Mask64 cbn_relu(const float* __restrict__ ab, int q, const f32x4 (&x)[16], float (&u)[64]) {
+    Mask64 m = {{0u, 0u}};
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ab + 16 * t + 4 * q);
@@ -252,11 +258,20 @@ __device__ __forceinline__ unsigned long long cbn_relu(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = fmaf(a[r], x[t][r], b[r]);
-            u[4 * t + r] = fmaxf(v, 0.f);
-            m |= (unsigned long long)(v > 0.f) << (4 * t + r);
+            const int ri = max(__float_as_int(v), 0);                  // ReLU on the bits (-0.0 and negatives -> +0)
+            u[4 * t + r] = __int_as_float(ri);
+            m.w[(4 * t + r) >> 5] = __builtin_amdgcn_alignbit(m.w[(4 * t + r) >> 5], (unsigned int)ri - 1u, 31);
         }
     }
+    asm volatile("" : "+v"(m.w[0]), "+v"(m.w[1]));     // keep them bit-masks
     return m;
+}
+// val where value k passed its ReLU, else +0
+__device__ __forceinline__ float relu_gate(const Mask64& m, int k, float val) {
+    const int dead = (int)(m.w[k >> 5] << (k & 31)) >> 31;            // v_bfe_i32: 0 / -1
+    unsigned int o;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(o) : "v"(dead), "v"(__float_as_uint(val)));      // val & ~dead
+    return __uint_as_float(o);
 }
 
 constexpr int OMODE_SUM = 0;      // d(sum of logits)/dp, loss = logits          (ifd_onet_decode)
@@ -272,7 +287,7 @@ __device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* 
     const float* ab = lds + OL_AB;
     f32x4 x[16], acc[16];
     float u[64];
-    unsigned long long m0[5], m1[5], mf;
+    Mask64 m0[5], m1[5], mf;
     // fc_p (decoder.py:118)
 #pragma unroll
     for (int t = 0; t < 16; ++t)
@@ -333,7 +348,7 @@ __device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* 
             const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
             const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_WOUT + 16 * t + 4 * q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[t][r] = ((mf >> (4 * t + r)) & 1ull) ? dl * w[r] * av[r] : 0.f;
+            for (int r = 0; r < 4; ++r) x[t][r] = relu_gate(mf, 4 * t + r, dl * w[r] * av[r]);
         }
     }
 #pragma unroll
@@ -352,7 +367,7 @@ __device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* 
             for (int t = 0; t < 16; ++t) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[4 * t + r] = ((m1[i] >> (4 * t + r)) & 1ull) ? acc[t][r] * av[r] : 0.f;
+                for (int r = 0; r < 4; ++r) u[4 * t + r] = relu_gate(m1[i], 4 * t + r, acc[t][r] * av[r]);
             }
         }
 #pragma unroll
@@ -365,7 +380,7 @@ __device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* 
                 const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    x[t][r] += ((m0[i] >> (4 * t + r)) & 1ull) ? acc[t][r] * av[r] : 0.f;
+                    x[t][r] += relu_gate(m0[i], 4 * t + r, acc[t][r] * av[r]);
             }
         }
     }
