@@ -263,7 +263,7 @@ __device__ __forceinline__ Mask64 cbn_relu(const float* __restrict__ ab, int q, 
             m.w[(4 * t + r) >> 5] = __builtin_amdgcn_alignbit(m.w[(4 * t + r) >> 5], (unsigned int)ri - 1u, 31);
         }
     }
-    asm volatile("" : "+v"(m.w[0]), "+v"(m.w[1]));     // keep them bit-masks
+    asm("" : "+v"(m.w[0]), "+v"(m.w[1]));     // keep them bit-masks (not volatile: dropped with the masks in forward-only passes)
     return m;
 }
 // val where value k passed its ReLU, else +0
