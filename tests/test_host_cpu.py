@@ -142,7 +142,7 @@ def test_world2_gloo_shard_and_allgather(tmp_path):
         "f = lambda shard, base, total: torch.from_numpy(shard * 2 + base * 0 + total * 0).float()\n"
         "out = D.defend_sharded(f, pc)\n"
         "assert out.shape == (7, 5, 3) and np.array_equal(out.numpy(), pc * 2), out\n"
-        "print('rank', rank, 'of', world, 'ok')\n" % ROOT)
+        "open(os.path.join(%r, 'ok_rank%%d_of_%%d' %% (rank, world)), 'w').write('ok')\n" % (ROOT, str(tmp_path)))
     import socket
     with socket.socket() as sk:                 # a free port (a fixed one fails when two test runs follow each other)
         sk.bind(("127.0.0.1", 0))
@@ -152,4 +152,5 @@ def test_world2_gloo_shard_and_allgather(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 of 2 ok" in r.stdout and "rank 1 of 2 ok" in r.stdout
+    # one marker file per rank (the two ranks' stdout lines interleave character by character)
+    assert (tmp_path / "ok_rank0_of_2").exists() and (tmp_path / "ok_rank1_of_2").exists(), r.stdout + r.stderr
