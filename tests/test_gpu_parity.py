@@ -3,7 +3,9 @@ against the golden fixtures produced by the reference and against the CPU oracle
 
 Tolerances (float32 path; north_star: 1e-3 per-point L2; SURVEY section 8c protocol P1-P4):
   logits / gradients   : relative 1e-4 of the tensor's max magnitude
-  P1 teacher-forced    : |dx| <= 1e-6 per coordinate for one Adam step from the oracle state
+  P1 teacher-forced    : |dx| <= 1e-6 per coordinate for one Adam step from the oracle state - every coordinate
+                         (measured max 3e-8), and the hot kernel's gradient itself (recovered from Adam's first
+                         moment) within 5e-6 of the reference autograd gradient's maximum (measured 4e-7 ... 6e-7)
   P2 free-running 10   : per-point L2 <= 1e-3 (the trajectory is chaotic - SURVEY F6)
   P4 sharding          : bitwise
 """
@@ -71,8 +73,9 @@ def test_repulsion_loss_knn_and_gradient(restorer, golden):
     np.testing.assert_allclose(loss.cpu().numpy(), golden["rep_loss_b"], rtol=1e-5)
     got, ref = idx.cpu().numpy(), golden["knn_idx"]
     same = np.array([[set(got[b, i]) == set(ref[b, i]) for i in range(1024)] for b in range(2)])
-    assert same.mean() > 0.999, same.mean()
-    assert (got == ref).mean() > 0.99          # and the same order (sorted by distance)
+    print("kNN: identical 5-NN sets %d of %d, identical order %.5f" % (same.sum(), same.size, (got == ref).mean()))
+    assert same.all()                           # measured: every one of the 2048 sets
+    assert (got == ref).mean() > 0.999          # and the same order (sorted by distance)
     pr = p.clone().requires_grad_()
     O.repulsion_loss(pr).sum().backward()
     assert _rel(grad.cpu().numpy(), pr.grad.numpy()) < 1e-4
@@ -107,7 +110,7 @@ def test_p1_teacher_forced_single_steps(restorer, golden, planes2):
         d = np.abs(out.cpu().numpy() - golden[f"traj{t}_x_next"])
         bad = d > 1e-6
         flips += int(bad.sum())
-        assert bad.mean() < 2e-3, (t, float(d.max()), int(bad.sum()))
+        assert bad.sum() == 0, (t, float(d.max()), int(bad.sum()))     # measured: 0 of 6144 at every t <= 50
         assert t1 == t + 1
     print("P1: coordinates off by > 1e-6 over 4 teacher-forced steps:", flips, "of", 4 * 2 * 1024 * 3)
 
@@ -123,7 +126,8 @@ def test_p1_late_steps_t100_t500_and_loss_batch(restorer, golden, planes2, oracl
         out, loss = restorer.optimize_points(torch.from_numpy(gl[f"traj{t}_x"]), planes2, rep_weight=500.0, steps=1,
                                              state=state, normalize=False, return_loss=True)
         d = np.abs(out.cpu().numpy() - gl[f"traj{t}_x_next"])
-        assert (d > 1e-6).mean() < 2e-3, (t, float(d.max()), int((d > 1e-6).sum()))
+        print("P1 t=%d: coordinates off by > 1e-6: %d of %d (max %.2e)" % (t + 1, (d > 1e-6).sum(), d.size, d.max()))
+        assert (d > 1e-6).sum() == 0, (t, float(d.max()), int((d > 1e-6).sum()))     # measured: 0 of 6144, max 3e-8
         loss = loss.cpu().numpy().astype(np.float64)
         np.testing.assert_allclose(loss[:, 0].sum() / 2, gl[f"traj{t}_loss"][0], rtol=1e-5)
         np.testing.assert_allclose(loss[:, 1].mean() * 500.0, gl[f"traj{t}_loss"][1], rtol=1e-4)
@@ -137,7 +141,7 @@ def test_p1_late_steps_t100_t500_and_loss_batch(restorer, golden, planes2, oracl
         got = restorer.optimize_points(x, planes2, rep_weight=500.0, steps=1, state=(m, v, 9), normalize=False,
                                        loss_batch=lb)
         d = np.abs(got.cpu().numpy() - ref.numpy())
-        assert (d > 1e-6).mean() < 2e-3, (lb, float(d.max()))
+        assert (d > 1e-6).sum() == 0, (lb, float(d.max()), int((d > 1e-6).sum()))
 
 
 def test_p2_free_running_10_and_50_steps(restorer, golden, planes2):
@@ -255,7 +259,8 @@ def test_sor_edge_sizes(restorer):
         pc = torch.randn(2, K, 3, generator=g)
         ref, _ = O.sor_keep_mask(pc)
         got = restorer.sor(pc).cpu().numpy().astype(bool)
-        assert (got == ref.numpy()).mean() > 0.9995, K              # fp64 threshold ties only
+        print("SOR K=%d: mask mismatches %d of %d" % (K, (got != ref.numpy()).sum(), got.size))
+        assert np.array_equal(got, ref.numpy()), K                   # boolean work on fp64 statistics: bit-exact
 
 
 def test_prepare_with_recorded_draws(restorer, golden):
@@ -564,7 +569,8 @@ def test_onet_p1_teacher_forced_and_p2_free_running(onet, og):
         state = (torch.from_numpy(og[f"traj{t}_m"]), torch.from_numpy(og[f"traj{t}_v"]), t)
         out = onet.optimize_points(x, c, rep_weight=500.0, steps=1, state=state, normalize=False)
         d = np.abs(out.cpu().numpy() - og[f"traj{t}_x_next"])
-        assert (d > 1e-6).mean() < 2e-3, (t, float(d.max()), int((d > 1e-6).sum()))
+        print("ONet P1 t=%d: coordinates off by > 1e-6: %d of %d" % (t + 1, (d > 1e-6).sum(), d.size))
+        assert (d > 1e-6).sum() == 0, (t, float(d.max()), int((d > 1e-6).sum()))     # measured: 0 of 6144
     x10 = onet.optimize_points(torch.from_numpy(og["traj0_x"]), c, rep_weight=500.0, steps=10, normalize=False)
     d10 = np.linalg.norm(x10.cpu().numpy() - og["traj9_x_next"], axis=-1)
     print("ONet P2: 10 steps max %.2e" % d10.max())
@@ -794,6 +800,88 @@ def test_onet_mesh_samples_match_oracle_distribution(onet, og):
     cd_self, cd_hip = _chamfer(a, b), 0.5 * (_chamfer(hip, a) + _chamfer(hip, b))
     print("ONet-Mesh samples: Chamfer HIP<->oracle %.4f, oracle seed<->seed %.4f" % (cd_hip, cd_self))
     assert cd_hip < 1.15 * cd_self
+
+
+# ------------------------------------------------------------------------------------------------
+# The hot tile's gradient, pinned directly (round 2).  `ifd_decode` runs the stand-alone decoder tile; the optimiser
+# runs the software-pipelined two-sub-tile one, which used to be checked only through Adam-normalised positions (a
+# ~1 % gradient error hides behind |dx| <= 1e-6 there).  One teacher-forced step with return_state gives m1 and v1:
+#   g = m0 + (m1 - m0) / (1 - beta1)      v1 = beta2 v0 + (1 - beta2) g^2
+# and that g is the hot kernel's total gradient (decoder tile + repulsion) - compared with the reference's autograd
+# gradient of the same step (fixtures traj{t}_g) at 1e-4 of its maximum.
+# ------------------------------------------------------------------------------------------------
+def _golden_file(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def _hot_gradient(restorer_, fixtures, cond, t):
+    x = torch.from_numpy(fixtures[f"traj{t}_x"])
+    m0, v0 = fixtures[f"traj{t}_m"], fixtures[f"traj{t}_v"]
+    out, (m1, v1, t1) = restorer_.optimize_points(x, cond, rep_weight=500.0, steps=1, normalize=False,
+                                                  state=(torch.from_numpy(m0), torch.from_numpy(v0), t), return_state=True)
+    m1, v1 = m1.cpu().numpy().astype(np.float64), v1.cpu().numpy().astype(np.float64)
+    g = m0 + (m1 - m0) / 0.1
+    return out.cpu().numpy(), g, v1
+
+
+@pytest.mark.parametrize("fixture,steps", [("convonet_golden.npz", (0, 1, 9, 49)), ("convonet_golden_long.npz", (99, 499)),
+                                           ("convonet_golden_seed1.npz", (0, 1, 9, 49, 99))])
+def test_hot_tile_gradient_against_reference_autograd(np_weights, fixture, steps):
+    import ifdefense_amd as I
+    from oracle import convonet_oracle as O
+    f = _golden_file(fixture)
+    if "seed1" in fixture:
+        r = I.Restorer(I.weights.pack_state_dict(O.make_random_weights(1)), device="cuda:0")
+        planes = {pl: torch.from_numpy(f["planes"][:, i]) for i, pl in enumerate(PL)}        # 4 clouds, B = 4
+    else:
+        r = I.Restorer(I.weights.pack_state_dict(np_weights), device="cuda:0")
+        g0 = _golden_file("convonet_golden.npz")
+        planes = {pl: torch.from_numpy(g0["planes01"][:, i]) for i, pl in enumerate(PL)}
+    try:
+        for t in steps:
+            x_next, g, v1 = _hot_gradient(r, f, planes, t)
+            g_ref = f[f"traj{t}_g"].astype(np.float64)
+            v_ref = 0.999 * f[f"traj{t}_v"].astype(np.float64) + 0.001 * g_ref ** 2
+            eg = np.abs(g - g_ref).max() / np.abs(g_ref).max()
+            ev = np.abs(v1 - v_ref).max() / np.abs(v_ref).max()
+            flips = int((np.abs(x_next - f[f"traj{t}_x_next"]) > 1e-6).sum())
+            print("%s t=%d: gradient rel. error %.2e, v1 rel. error %.2e, coordinates off by > 1e-6: %d of %d" %
+                  (fixture, t, eg, ev, flips, x_next.size))
+            # measured on MI355X (round 2): gradient 4e-7 ... 6e-7 of its maximum at every t and both weight seeds, v1
+            # 1e-5 (t = 0, where v1 = 0.001 g^2 is recovered from a difference) ... 7e-8, and not one coordinate off by
+            # more than 1e-6 after the Adam update (max 3e-8) - the bars sit ~10x above the measured values
+            assert eg < 5e-6 and ev < 1e-4, (fixture, t, eg, ev)
+            assert flips == 0, (fixture, t, flips)
+    finally:
+        r.close()
+
+
+def test_hot_tile_gradient_onet(onet, og):
+    c = torch.from_numpy(og["c"][:2])
+    for t in (0, 1, 9):
+        x_next, g, v1 = _hot_gradient(onet, og, c, t)
+        g_ref = og[f"traj{t}_g"].astype(np.float64)
+        # 22 ReLUs x 256 channels per point: a pre-activation within rounding of zero flips a mask bit (see
+        # test_onet_decode_logits_and_input_gradient) - per point, relative to the largest gradient
+        dg = np.abs(g - g_ref).max(-1) / np.abs(g_ref).max()
+        print("ONet t=%d: gradient error median %.2e max %.2e, points > 1e-4: %d" % (t, np.median(dg), dg.max(), (dg > 1e-4).sum()))
+        assert (dg > 1e-4).sum() <= 2 and np.median(dg) < 5e-7 and dg.max() < 2e-3, (t, dg.max())   # measured: <= 1 point, max 4e-4
+
+
+def test_decode_second_weight_seed(np_weights):
+    """G2 on the second parity base: logits and d(sum logits)/dp of the stand-alone tile, 4 clouds, weight seed 1."""
+    import ifdefense_amd as I
+    from oracle import convonet_oracle as O
+    f = _golden_file("convonet_golden_seed1.npz")
+    r = I.Restorer(I.weights.pack_state_dict(O.make_random_weights(1)), device="cuda:0")
+    try:
+        planes = {pl: torch.from_numpy(f["planes"][:, i]) for i, pl in enumerate(PL)}
+        logits, grad = r.decode(torch.from_numpy(f["traj0_x"]), planes, want_grad=True)
+        assert _rel(logits.cpu().numpy(), f["dec_logits"]) < 1e-5
+        assert _rel(grad.cpu().numpy(), f["dec_dlogit_dp"]) < 1e-4
+    finally:
+        r.close()
 
 
 def test_lists_equal_scan_on_mixed_inputs(restorer):
