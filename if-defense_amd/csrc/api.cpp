@@ -90,6 +90,8 @@ struct ifd_ctx {
     unsigned long long* d_counters = nullptr;   // IFD_N_COUNTERS diagnostic counters of the last ifd_optimize
     void* ws = nullptr;            // context-owned scratch (kNN lists, encoder activations), grown on demand
     size_t ws_bytes = 0;
+    void* adam_tab = nullptr;      // per-step Adam bias corrections of the current optimise call (launch_adam_table)
+    size_t adam_bytes = 0;
     // ONet-Opt variant (ifd_onet_create): padded copy of the canonical weights, fragment-ordered decoder layer images
     // (10 forward + 10 transposed), the small decoder parameters, tensor offsets into d_w
     int model = IFD_MODEL_CONVONET;
@@ -133,6 +135,17 @@ std::vector<float> build_dec_image(const float* w) {
         img[DEC_OFF_WOUT + c] = w[m.dec_out_w + c];
     }
     img[DEC_OFF_BOUT] = w[m.dec_out_b];
+    // The bias of fc_c[i] only ever enters through a_i = n_i + fc_c[i](c), and n_i only through a_i: fold it into the bias
+    // that produced n_i (fc_p's for i = 0, blocks[i-1].fc_1's otherwise), so that the MFMA chain of fc_c[i] starts from
+    // the accumulators of n_i as they are (one vector add per layer and point saved in the tiles).
+    for (int c = 0; c < 32; ++c) {
+        img[DEC_OFF_WP + c * 4 + 3] += img[DEC_OFF_BIAS + 0 * 32 + c];
+        img[DEC_OFF_BIAS + 0 * 32 + c] = 0.f;
+        for (int i = 1; i < 5; ++i) {
+            img[DEC_OFF_BIAS + (3 * (i - 1) + 2) * 32 + c] += img[DEC_OFF_BIAS + 3 * i * 32 + c];
+            img[DEC_OFF_BIAS + 3 * i * 32 + c] = 0.f;
+        }
+    }
     return img;
 }
 
@@ -350,6 +363,7 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (!ctx) return;
     if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_w) (void)hipFree(ctx->d_w);
     if (ctx->d_unet) (void)hipFree(ctx->d_unet);
@@ -461,11 +475,13 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;
     hipError_t e = ensure_ws(ctx, knn_list_bytes(B));
+    if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
     e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset", e);
-    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K,
-                        a, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
+    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, static_cast<uint16_t*>(ctx->ws), ctx->d_counters,
+                        static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
 }
 
@@ -626,13 +642,16 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = ensure_ws(ctx, knn_list_bytes(B));
+    if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_optimize workspace", e);
     float* ab = nullptr;
     e = onet_fold(ctx, c, B, s, &ab);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, s);
     if (e == hipSuccess)
         e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
-                                 static_cast<uint16_t*>(ctx->ws), ctx->d_counters, B, K, a, s);
+                                 static_cast<uint16_t*>(ctx->ws), ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K,
+                                 a, s);
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_onet_optimize", e);
 }
 

@@ -44,8 +44,10 @@ hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, co
 
 hipError_t configure_optimize_kernels();
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                           const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters, int B, int K, const OptArgs& a,
-                           hipStream_t s);
+                           const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters,
+                           const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s);
+// per-step Adam bias corrections {lr / (1 - beta1^t), sqrt(1 - beta2^t)}, t = t0 + 1 ... t0 + steps -> tab[steps][2]
+hipError_t launch_adam_table(float* tab, int t0, int steps, float lr, hipStream_t s);
 // bytes of context workspace ifd_optimize needs for B clouds (certified neighbour lists)
 size_t knn_list_bytes(int B);
 hipError_t launch_decode(const float* dec_img, const float* planes, const float* p, int B, int K, float* logits,
@@ -73,7 +75,8 @@ hipError_t launch_onet_decode(const float* img, const float* small, const float*
                               float* logits, float* dlogit_dp, hipStream_t s);
 hipError_t launch_onet_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
                                 float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
-                                unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s);
+                                unsigned long long* counters, const float* adam_tab, int B, int K, const OptArgs& a,
+                                hipStream_t s);
 
 // ---- ONet-Mesh (mesh.hip) --------------------------------------------------------------------------------
 // MISE state of a batch of clouds as dense arrays (per-cloud strides: P3 for val / known, pend_stride for pend,

@@ -78,6 +78,27 @@ constexpr int LIST_F = 16;               // "front": every point within rho_f at
 constexpr int LIST_B = 32;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
 constexpr int LIST_M = LIST_F + LIST_B;  // uint16 entries per point; lists live in global memory (L2-resident)
 
+// Per-step diagnostics of the kNN phase: event counts live in LDS (one atomic by lane 0 per event - they are rare or
+// once per wave-step), not in registers that would have to survive the decoder tiles.  Summed into ifd_get_counters.
+enum { CN_REBUILD = 0, CN_BRUTE, CN_PASS, CN_TIER2, CN_EXACT, CN_REFRESH, CN_TARGETS, CN_COUNT };
+struct KnnCounters {
+    unsigned int* lds;       // [CN_COUNT]
+    int lane;
+    __device__ __forceinline__ void bump(int which, unsigned int n = 1u) const {
+        if (lane == 0) atomicAdd(lds + which, n);
+    }
+#ifdef IFD_PROF      // cycle accounting (diagnostic builds only)
+    unsigned long long pc_build = 0, pc_eval = 0, pc_rep = 0, pc_tiles = 0, pc_wait = 0, pc_adam = 0, pc_t = 0;
+#endif
+};
+#ifdef IFD_PROF
+#define PROF_T0() cn.pc_t = __builtin_readcyclecounter()
+#define PROF_ACC(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); cn.v += n_ - cn.pc_t; cn.pc_t = n_; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ACC(v)
+#endif
+
 // 5 nearest of points ia / ib among entries [E0, E1) of their lists, continuing the running top-5 in ta / tb.
 // The two independent insertion chains are interleaved for ILP.  Entries >= cnt are ignored.
 template <int E0, int E1>
@@ -275,7 +296,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, int wave, int lane,
                                             uint16_t* __restrict__ lists, bool need_a, bool need_b, float d4a,
                                             float d4b, KnnPt& ka, KnnPt& kb, float dbase, float mv,
-                                            unsigned int& n_targets, unsigned int& n_repass) {
+                                            const KnnCounters& cn) {
     float cx[16], cy[16], cz[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -299,12 +320,12 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
             const f32x4 xi = X[i];                                                   // wave-uniform address
             uint16_t* lst = lists + (size_t)i * LIST_M;
             int nf, nb;
-            ++n_targets;
+            cn.bump(CN_TARGETS);
 #pragma unroll 1
             for (int rep = 0;; ++rep) {
                 knn_build_one(cx, cy, cz, xi, i, lane, tf, tb, lst, nf, nb);
                 if ((nf <= LIST_F && nb <= LIST_B) || rep == 3) break;
-                ++n_repass;
+                cn.bump(CN_PASS);
                 const float n_in = (float)(min(nf, LIST_F) + nb);                   // points inside the back radius
                 float nf_new = (float)nf;
                 if (nf > LIST_F) { tf *= (0.7f * LIST_F) / (float)nf; nf_new = 0.7f * LIST_F; }
@@ -448,15 +469,16 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
 
 // The two owned points together (optimiser): one instruction stream with the two independent chains interleaved -
 // two rep_point calls under separate `if (p < K)` branches cannot overlap their LDS / sqrt / exp / divide latencies.
+// The centre's own share (minus what its five neighbours receive) goes into F with the same fixed-point atomics: integer
+// addition commutes, so F[i] ends up as the same sum whatever the order, and no register has to carry it to the Adam phase.
 __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, long long* __restrict__ F, int K, int pa, int pb,
                                            const Top5& ta, const Top5& tb, const RepConst rc, float& loss_a,
-                                           float& loss_b, long long (&gca)[3], long long (&gcb)[3]) {
+                                           float& loss_b) {
     const bool va = pa < K, vb = pb < K;
     const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
     const int ia[5] = {ta.i0, ta.i1, ta.i2, ta.i3, ta.i4}, ib[5] = {tb.i0, tb.i1, tb.i2, tb.i3, tb.i4};
     float la = 0.f, lb = 0.f;
-    gca[0] = gca[1] = gca[2] = 0;
-    gcb[0] = gcb[1] = gcb[2] = 0;
+    long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int ja = va ? ia[k] : 0, jb = vb ? ib[k] : 0;
@@ -492,6 +514,14 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, long lon
                 atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * jb + a), (unsigned long long)f[1][a]);
             }
         }
+    }
+    if (va) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * pa + a), (unsigned long long)gca[a]);
+    }
+    if (vb) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * pb + a), (unsigned long long)gcb[a]);
     }
     loss_a = la;
     loss_b = lb;
@@ -556,21 +586,6 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
 }
 
 
-// Per-step diagnostics of the kNN phase (summed into ifd_get_counters by the kernels).
-struct KnnCounters {
-    unsigned int n_rebuild = 0, n_brute = 0, n_pass = 0, n_tier2 = 0, n_exact = 0, n_refresh = 0, n_targets = 0;
-#ifdef IFD_PROF      // cycle accounting (diagnostic builds only)
-    unsigned long long pc_build = 0, pc_eval = 0, pc_rep = 0, pc_tiles = 0, pc_wait = 0, pc_adam = 0, pc_t = 0;
-#endif
-};
-#ifdef IFD_PROF
-#define PROF_T0() cn.pc_t = __builtin_readcyclecounter()
-#define PROF_ACC(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); cn.v += n_ - cn.pc_t; cn.pc_t = n_; } while (0)
-#else
-#define PROF_T0()
-#define PROF_ACC(v)
-#endif
-
 // Block-shared scalars of the neighbour-list protocol (LDS).
 struct KnnShared {
     float* dmaxbuf;                  // [2][MAX_WAVES] per-wave max displacement from the epoch reference (next step)
@@ -579,13 +594,12 @@ struct KnnShared {
 };
 
 // kNN + repulsion of the two points (pa, pb) this lane owns, for one optimiser step (all lanes of an owner wave call
-// it together).  Leaves the loss terms in rep_loss_a/b, the centre gradients in gca/gcb (fixed point) and scatters
-// the neighbour gradients into F.
+// it together).  Leaves the loss terms in rep_loss_a/b and scatters the neighbour AND centre gradients into F (fixed point).
 __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long* __restrict__ F, int K, int pa, int pb,
                                           int wave, int lane, int step, bool last, bool scan_every_step,
                                           const uint16_t* La, const uint16_t* Lb, uint16_t* cloud_lists, KnnPt& ka,
                                           KnnPt& kb, const KnnShared& sh, const RepConst rc, float& rep_loss_a,
-                                          float& rep_loss_b, long long (&gca)[3], long long (&gcb)[3], KnnCounters& cn) {
+                                          float& rep_loss_b, KnnCounters& cn) {
     float* const dmaxbuf = sh.dmaxbuf;
     float* const movebuf = sh.movebuf;
     volatile int* const rebuild_flag = sh.rebuild_flag;
@@ -612,7 +626,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
             float d4a, d4b;        // upper bounds of the squared 5-NN distances at the current positions
             if (force) {
                 // ---- synchronous whole-cloud rebuild (every owner wave, this step): new epoch ---------
-                ++cn.n_rebuild;
+                cn.bump(CN_REBUILD);
                 // any 5 members of the current lists (a truncated ring still holds valid points), else scan
                 bool have = step != 0;
                 if (have) {
@@ -627,7 +641,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                     have = ta.d4 < 1e30f && tb.d4 < 1e30f;       // the dummy point is ~3e36 away
                 }
                 if (!__all(have)) {
-                    ++cn.n_pass;
+                    cn.bump(CN_PASS);
                     knn_scan2(X, K, pa, pb, ta, tb);
                 }
                 d4a = ta.d4;
@@ -635,13 +649,12 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                 dmax = 0.f;
             } else {
                 // ---- individual refresh of fragile certificates: r5 grows by at most 2 mv per step ----
-                ++cn.n_refresh;
+                cn.bump(CN_REFRESH);
                 const float ra = ka.r5p + 2.f * mv, rb = kb.r5p + 2.f * mv;
                 d4a = ra * ra;
                 d4b = rb * rb;
             }
-            knn_refresh(X, K, wave, lane, cloud_lists, need_a, need_b, d4a, d4b, ka, kb, dmax, mv,
-                        cn.n_targets, cn.n_pass);
+            knn_refresh(X, K, wave, lane, cloud_lists, need_a, need_b, d4a, d4b, ka, kb, dmax, mv, cn);
         }
         ka.pend = kb.pend = false;
         PROF_ACC(pc_build);
@@ -671,7 +684,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                              (pb >= K || r5b < (kb.rho_f - hs_b) * 0.99999f - 1e-7f);
             bool fail_a = false, fail_b = false;      // hard certificate failures (only possible once the ring was needed)
             if (!__all(ok1)) {
-                ++cn.n_tier2;
+                cn.bump(CN_TIER2);
                 list_keys6_2<LIST_F / 8, LIST_M / 8>(X, wa, wb, ia, ib, qa, qb);
                 r5a = sqrtf(key_d_upper(qa.k4));
                 r5b = sqrtf(key_d_upper(qb.k4));
@@ -688,14 +701,14 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                 keys6_to_top5(qa, ta);
                 keys6_to_top5(qb, tb);
                 if (__builtin_expect(__any(fail_a || fail_b), 0)) {       // certificate failed: exact query for those points, this step
-                    ++cn.n_brute;
+                    cn.bump(CN_BRUTE);
                     knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
             }
         }
         if (exact) {
             // ---- exact path: sorted insertion with indices (last step, near-ties) --------------------
-            ++cn.n_exact;
+            cn.bump(CN_EXACT);
             soft_a = soft_b = true;
             top5_init(ta);
             top5_init(tb);
@@ -708,7 +721,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                 const bool fail_a = pa < K && !(ka.cnt_b >= 0 && r5a < (ka.rho_b - hs_a) * 0.99999f - 1e-7f);
                 const bool fail_b = pb < K && !(kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f);
                 if (__builtin_expect(__any(fail_a || fail_b), 0)) {
-                    ++cn.n_brute;
+                    cn.bump(CN_BRUTE);
                     knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
                 soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
@@ -725,33 +738,30 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
         if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
         PROF_ACC(pc_eval);
     }
-    rep_point2(X, F, K, pa, pb, ta, tb, rc, rep_loss_a, rep_loss_b, gca, gcb);
+    rep_point2(X, F, K, pa, pb, ta, tb, rc, rep_loss_a, rep_loss_b);
     PROF_ACC(pc_rep);
 }
 
 // Adam state of the two owned points (torch.optim.Adam keeps exp_avg / exp_avg_sq per coordinate).
 struct AdamState {
     float mm[6], vv[6];
-    double b1t, b2t;         // beta^t, accumulated in double like torch's Python scalars
 };
 
 // Fused Adam update of the two owned points (torch/optim/adam.py _single_tensor_adam).  G: occupancy gradient,
-// F + gca/gcb: repulsion gradient in fixed point (scaled by rep_scale).  Also reduces this wave's displacement /
-// step-length maxima for the neighbour-list certificates of the next step.
+// F: repulsion gradient in fixed point, centre and neighbour terms (scaled by rep_scale).  step_size = lr / (1 - beta1^t)
+// and bc2 = sqrt(1 - beta2^t) come from a per-step table the host computes in double like torch's Python scalars
+// (adam_table in api.cpp).  Also reduces this wave's displacement / step-length maxima for the neighbour-list
+// certificates of the next step.
 __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* __restrict__ G, long long* __restrict__ F,
-                                           int K, int pa, int pb, int wave, int lane, int step, float lr,
-                                           float rep_scale, const long long (&gca)[3], const long long (&gcb)[3],
-                                           AdamState& st, const KnnPt& ka, const KnnPt& kb, const KnnShared& sh) {
+                                           int K, int pa, int pb, int wave, int lane, int step, float step_size,
+                                           float bc2, float rep_scale, AdamState& st, const KnnPt& ka, const KnnPt& kb,
+                                           const KnnShared& sh) {
     float* const dmaxbuf = sh.dmaxbuf;
     float* const movebuf = sh.movebuf;
     float (&mm)[6] = st.mm;
     float (&vv)[6] = st.vv;
     // ---- Adam (torch/optim/adam.py _single_tensor_adam: lerp form, eps added after the bias-
     //      corrected sqrt) ---------------------------------------------------------------------
-    st.b1t *= 0.9;
-    st.b2t *= 0.999;
-    const float step_size = (float)((double)lr / (1.0 - st.b1t));
-    const float bc2 = (float)sqrt(1.0 - st.b2t);
     float dmax2 = 0.f, mv2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -764,7 +774,7 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             float msq = 0.f;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float gn = __ll2float_rn(F[3 * pt + a] + (q ? gcb[a] : gca[a])) * FIX_INV;
+                const float gn = __ll2float_rn(F[3 * pt + a]) * FIX_INV;
                 F[3 * pt + a] = 0;
                 const float gr = gn * rep_scale;
                 const float g = gocc[a] + gr;
@@ -782,7 +792,7 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
                               (xs[2] - x0.z) * (xs[2] - x0.z);
             dmax2 = fmaxf(dmax2, sqrtf(dsq) + (q ? kb.dbase : ka.dbase));
             mv2 = fmaxf(mv2, msq);
-            X[pt] = f32x4{xs[0], xs[1], xs[2], 0.f};
+            X[pt] = f32x4{xs[0], xs[1], xs[2], 1.f};     // .w = 1: fc_p's bias input on the matrix pipe (optimize.hip)
         }
     }
     dmax2 = wave_max(dmax2);
@@ -791,6 +801,48 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
         dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = dmax2 * 1.00001f + 1e-7f;
         movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parking: per-thread state that must survive a register-hungry phase is written to a private (scratch) array by hand,
+// in one batch of 16-byte stores, and read back in one batch - instead of leaving it to the register allocator, which
+// spills such values one by one and reloads them lazily, each with its own memory round trip, inside the latency-bound
+// phases (and whose choices move by +-15 % with semantically neutral edits).  The slot index goes through an opaque zero
+// (one per park / unpark site, with a memory clobber), so the compiler can neither promote the array to registers nor
+// forward a store to the matching load.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z) : : "memory");
+    return z;
+}
+constexpr int PARK_KNN = 0;       // 4 slots per KnnPt: ka at 0, kb at 4
+constexpr int PARK_ADAM = 8;      // 3 slots: mm[6], vv[6]
+constexpr int PARK_SLOTS = 11;
+
+__device__ __forceinline__ void park_knnpt(f32x4* park, int z, int base, const KnnPt& k) {
+    park[z + base + 0] = f32x4{__int_as_float(k.cnt_f), __int_as_float(k.cnt_b), k.rho_f, k.rho_b};
+    park[z + base + 1] = f32x4{k.al_f, k.al_b, k.dbase, k.r5p};
+    park[z + base + 2] = f32x4{k.x0.x, k.x0.y, k.x0.z, __int_as_float((k.frag ? 1 : 0) | (k.pend ? 2 : 0))};
+}
+__device__ __forceinline__ void unpark_knnpt(const f32x4* park, int z, int base, KnnPt& k) {
+    const f32x4 a = park[z + base + 0], b = park[z + base + 1], c = park[z + base + 2];
+    k.cnt_f = __float_as_int(a.x); k.cnt_b = __float_as_int(a.y); k.rho_f = a.z; k.rho_b = a.w;
+    k.al_f = b.x; k.al_b = b.y; k.dbase = b.z; k.r5p = b.w;
+    k.x0 = f32x4{c.x, c.y, c.z, 0.f};
+    const int fl = __float_as_int(c.w);
+    k.frag = (fl & 1) != 0;
+    k.pend = (fl & 2) != 0;
+}
+__device__ __forceinline__ void park_adam(f32x4* park, int z, const AdamState& st) {
+    park[z + PARK_ADAM + 0] = f32x4{st.mm[0], st.mm[1], st.mm[2], st.mm[3]};
+    park[z + PARK_ADAM + 1] = f32x4{st.mm[4], st.mm[5], st.vv[0], st.vv[1]};
+    park[z + PARK_ADAM + 2] = f32x4{st.vv[2], st.vv[3], st.vv[4], st.vv[5]};
+}
+__device__ __forceinline__ void unpark_adam(const f32x4* park, int z, AdamState& st) {
+    const f32x4 a = park[z + PARK_ADAM + 0], b = park[z + PARK_ADAM + 1], c = park[z + PARK_ADAM + 2];
+    st.mm[0] = a.x; st.mm[1] = a.y; st.mm[2] = a.z; st.mm[3] = a.w; st.mm[4] = b.x; st.mm[5] = b.y;
+    st.vv[0] = b.z; st.vv[1] = b.w; st.vv[2] = c.x; st.vv[3] = c.y; st.vv[4] = c.z; st.vv[5] = c.w;
 }
 
 }  // namespace ifd

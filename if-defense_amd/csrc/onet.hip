@@ -489,8 +489,8 @@ hipError_t launch_onet_grid_eval(const float* img, const float* small, const flo
 __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
     const float* __restrict__ img, const float* __restrict__ small, const float* __restrict__ ab, float* __restrict__ p,
     float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
-    const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* __restrict__ counters, int K,
-    OptArgs A) {
+    const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* __restrict__ counters,
+    const float* __restrict__ adam_tab, int K, OptArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* G = reinterpret_cast<f32x4*>(smem + OL_G);                // occupancy gradient (+ BCE term in .w)
     f32x4* X = G + MAXK;                                             // current points; X[MAXK] = far-away dummy
@@ -526,8 +526,6 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
     const float inv_lb = 1.0f / (float)loss_batch;
     const float rep_scale = A.rep_weight / ((float)loss_batch * (float)K * 5.f);
     const bool use_rep = A.rep_weight > 0.f;
-    ast.b1t = pow(0.9, (double)A.t0);
-    ast.b2t = pow(0.999, (double)A.t0);
     float rep_loss_a = 0.f, rep_loss_b = 0.f;
     uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;
     uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + (pb & (MAXK - 1))) * LIST_M;
@@ -537,19 +535,20 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
     float* dmaxbuf = scratch + 32;
     float* movebuf = scratch + 64;
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);
-    KnnCounters cn;
+    unsigned int* lcnt = reinterpret_cast<unsigned int*>(scratch + 96);           // [CN_COUNT] event counters
+    KnnCounters cn{lcnt, lane};
     const KnnShared ksh = {dmaxbuf, movebuf, rebuild_flag};
     if (tid < 2) rebuild_flag[tid] = 0;
+    if (tid < CN_COUNT) lcnt[tid] = 0u;
     if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
     onet_prologue(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);   // syncs
 
     const int npass = (K + 127) >> 7;
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
-        long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
         if (use_rep)
             knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb, ksh,
-                      rc, rep_loss_a, rep_loss_b, gca, gcb, cn);
+                      rc, rep_loss_a, rep_loss_b, cn);
 #pragma unroll 1
         for (int g = 0; g < npass; ++g) {
             const int pt = g * 128 + wave * 16 + (lane & 15), tp = min(pt, K - 1);
@@ -573,19 +572,17 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
         }
-        adam_phase(X, G, F, K, pa, pb, wave, lane, step, A.lr, rep_scale, gca, gcb, ast, ka, kb, ksh);
+        adam_phase(X, G, F, K, pa, pb, wave, lane, step, adam_tab[2 * step], adam_tab[2 * step + 1], rep_scale, ast, ka, kb,
+                   ksh);
         if (tid == 0) rebuild_flag[step & 1] = 0;
         __syncthreads();
     }
 
-    if (counters != nullptr && lane == 0) {
-        atomicAdd(counters + 0, (unsigned long long)cn.n_rebuild);
-        atomicAdd(counters + 1, (unsigned long long)cn.n_brute);
-        atomicAdd(counters + 2, (unsigned long long)cn.n_pass);
-        atomicAdd(counters + 4, (unsigned long long)cn.n_tier2);
-        atomicAdd(counters + 5, (unsigned long long)cn.n_exact);
-        atomicAdd(counters + 6, (unsigned long long)cn.n_refresh);
-        atomicAdd(counters + 7, (unsigned long long)cn.n_targets);
+    if (counters != nullptr) {
+        if (tid < CN_COUNT) {
+            constexpr int SLOT[CN_COUNT] = {0, 1, 2, 4, 5, 6, 7};
+            atomicAdd(counters + SLOT[tid], (unsigned long long)lcnt[tid]);
+        }
         if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
@@ -621,10 +618,10 @@ hipError_t launch_onet_decode(const float* img, const float* small, const float*
 }
 
 hipError_t launch_onet_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v, float* loss,
-                                const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters, int B,
-                                int K, const OptArgs& a, hipStream_t s) {
+                                const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters,
+                                const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(onet_optimize_kernel, dim3(B), dim3(OPT_THREADS), ONET_OPT_LDS, s, img, small, ab, p, m, v, loss,
-                       loss_batch_per_cloud, knn_lists, counters, K, a);
+                       loss_batch_per_cloud, knn_lists, counters, adam_tab, K, a);
     return hipGetLastError();
 }
 

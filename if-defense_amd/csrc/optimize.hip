@@ -351,35 +351,20 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 // The taps are gathered one plane at a time and re-gathered for the backward pass (L1/L2 hits): holding them
 // for two sub-tiles would need 192 VGPRs.
 // ---------------------------------------------------------------------------------------------
-// Bit (7 - r) of the result = "value r is NOT positive": the sign of (bits(relu(v)) - 1) shifted in with one v_alignbit
-// per value (relu(v) = +0 -> 0xffffffff, any positive float -> a positive integer).  Exact at +-0 like v > 0.
-__device__ __forceinline__ uint32_t mask_pos_packed(const f32x8& v) {
+// ReLU masks of the optimiser tile.  One v_alignbit per value shifts the SIGN bit of the pre-activation into the mask
+// word (value r -> bit 7 - r), the word is inverted once, and the backward pass applies it with v_bfe_i32 (bit -> 0 / -1)
+// + v_and.  "Alive" therefore means sign bit clear: v > 0 or v == +0.0 - torch's threshold_backward uses v > 0, so the
+// two differ only for a pre-activation that is exactly +0.0 (forward values are identical; the one structural case,
+// a zero bias under an all-dead input, sits under a dead outer mask).  Integer and bit-field instructions cost ~6
+// SIMD cycles each next to the f32 MFMAs (scripts/valu_rates.hip), v_and / v_add / v_fma ~4.5: the earlier exact-at-+0
+// form (v_max, v_add -1, v_alignbit | v_bfe, v_bfi) was 29 cycles per value, this one is 24.
+__device__ __forceinline__ uint32_t mask_alive_packed(const f32x8& v) {
     uint32_t m = 0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const uint32_t t = (uint32_t)max(__float_as_int(v[r]), 0) - 1u;
-        m = __builtin_amdgcn_alignbit(m, t, 31);
-    }
+    for (int r = 0; r < 8; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(v[r]), 31);
+    m = ~m;
     asm volatile("" : "+v"(m));
     return m;
-}
-
-struct SubGeo {                      // per-point sampling geometry of one sub-tile lane
-    float x[3], w0[3], w1[3], live[3];
-    int cell[3];
-};
-
-__device__ __forceinline__ void sub_geometry(SubGeo& g, float x0, float x1, float x2, const DecConst& dc) {
-    g.x[0] = x0; g.x[1] = x1; g.x[2] = x2;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float pix;
-        pixel_coord(g.x[a], dc, pix, g.live[a]);
-        const int ci = min((int)floorf(pix), RES - 2);
-        g.cell[a] = ci;
-        g.w1[a] = pix - (float)ci;
-        g.w0[a] = ((float)ci + 1.f) - pix;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,53 +442,124 @@ __device__ __forceinline__ Acc2 acc_zero() {
     r.t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     return r;
 }
-__device__ __forceinline__ f32x8 masked(const Acc2& z, uint32_t m) {
+__device__ __forceinline__ f32x8 masked(const Acc2& z, uint32_t alive) {
     f32x8 v = flat(z);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        uint32_t dead, o;                                         // v_bfe_i32: 0 / -1 ; v_bfi: v & ~dead
-        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(dead) : "v"(m), "n"(7 - r));
-        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(o) : "v"(dead), "v"(__float_as_uint(v[r])));
-        v[r] = __uint_as_float(o);
+        uint32_t keep;                                            // v_bfe_i32: 0 / -1
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(alive), "n"(7 - r));
+        v[r] = __uint_as_float(__float_as_uint(v[r]) & keep);
     }
     return v;
 }
 
+// ---- sampling coordinates, once per point and step ---------------------------------------------------------------
+// The owner thread of a point turns its coordinates into the three pixel coordinates of grid_sample (pixel_coord above:
+// normalize_coordinate's divide / clamp, align_corners un-normalisation, border clip) when it writes the point - at
+// start-up and in the Adam phase - and keeps them in LDS (PIX).  A coordinate that normalize_coordinate clamped carries
+// a minus sign (its plane gradient is zero; -0.0 for the lower clamp).  In a decoder tile four lanes share a point, so
+// there the same arithmetic costs a whole wave instruction per 16 points; in the Adam phase one per 64.
+__device__ __forceinline__ f32x4 pix_encode(float x0, float x1, float x2, const DecConst& dc) {
+    const float xs[3] = {x0, x1, x2};
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float pix, live;
+        pixel_coord(xs[a], dc, pix, live);
+        o[a] = live != 0.f ? pix : __uint_as_float(__float_as_uint(pix) | 0x80000000u);
+    }
+    return o;
+}
+
+struct SubGeo {                      // per-point sampling geometry of one sub-tile lane
+    float w0[3], w1[3], lk[3];       // bilinear weights per axis; d pix / d x (0 for a clamped coordinate)
+    int cell[3];
+};
+
+__device__ __forceinline__ void sub_geometry(SubGeo& g, const f32x4 pp, float ksc) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ap = fabsf(pp[a]);
+        const int ci = min((int)ap, RES - 2);       // pix >= 0: truncation is floor
+        const float cf = (float)ci;
+        g.cell[a] = ci;
+        g.w1[a] = ap - cf;                           // weight of the east / south tap
+        g.w0[a] = (cf + 1.f) - ap;                   // weight of the west / north tap
+        g.lk[a] = (int)__float_as_uint(pp[a]) < 0 ? 0.f : ksc;
+    }
+}
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
 template <int MODE>
-__device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const float* __restrict__ planes,
-                                              const f32x4 xa, const f32x4 xb, int lane, const DecConst dc, float thr,
-                                              float inv_lb, float (&bce)[2], float (&dx)[2][3]) {
+__device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amdgpu_buffer_rsrc_t planes,
+                                              const float* __restrict__ planes_ptr, const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, const f32x4 xfa,
+                                              const f32x4 xfb, int lane,
+                                              const DecConst dc, float thr, float inv_lb, bool want_loss,
+                                              float (&bce)[2], float (&dx)[2][3]) {
+#ifndef IFD_TV
+#define IFD_TV 1
+#endif
+    constexpr int TV = IFD_TV;
     const int n = lane & 15, q = lane >> 4;
     LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
     asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
     constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
+    // d pix / d x = (RES - 1) / 2 * 2 / sdiv as one constant (the reference multiplies and divides in sequence; the
+    // difference is a rounding in the last place of a gradient term)
+    const float ksc = ((0.5f * (float)(RES - 1)) * 2.f) / dc.sdiv;
     SubGeo geo[2];
-    sub_geometry(geo[0], xa.x, xa.y, xa.z, dc);
-    sub_geometry(geo[1], xb.x, xb.y, xb.z, dc);
+    sub_geometry(geo[0], ppa, ksc);
+    sub_geometry(geo[1], ppb, ksc);
     const float* Wd = W + DEC_OFF_W;
+    // bias rows through their own base register: the image is > 64 KB, past the reach of a DS immediate offset
+    int boff = DEC_OFF_BIAS + lo.q4;             // (opaque as an integer: an opaque POINTER loses its LDS address space)
+    asm volatile("" : "+v"(boff));
+    const float* Bq = W + boff;
+    auto bias = [&](int layer) {
+        Acc2 b;
+        b.t[0] = *reinterpret_cast<const f32x4*>(Bq + layer * 32);
+        b.t[1] = *reinterpret_cast<const f32x4*>(Bq + layer * 32 + 16);
+        return b;
+    };
 
-
-    // ---- gather + forward bilinear sample, one plane (2 x 8 loads) at a time ---------------------------------
+    // ---- gather + forward bilinear sample ----------------------------------------------------------------------
+    // The taps come from HBM / Infinity Cache (L2 hit rate 37 %): one round trip per plane would cost ~1.5 us each, so
+    // the loads of all planes are in flight at once (64 tap registers per plane).  Buffer loads: the cloud's plane
+    // base sits in the SGPR resource, the lane supplies a 32-bit byte offset - no 64-bit address arithmetic.
     f32x8 c[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
-    // The taps come from HBM / Infinity Cache (L2 hit rate 37 %): one round trip per plane would cost ~1.5 us each, so
-    // the loads of several planes are in flight at once (64 tap registers per plane).
+    const int q16 = 16 * q;
     auto load_taps = [&](int P, f32x4 (&tap)[2][4][2], bool opaque) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            int off = ((P * RES + geo[t].cell[a1]) * RES + geo[t].cell[a0]) * CH + 4 * q;
+            int off = (geo[t].cell[a1] * RES + geo[t].cell[a0]) * (CH * 4) + (P * PLANE_FLOATS * 4 + q16);
             if (opaque) asm volatile("" : "+v"(off));      // backward re-gather: do not CSE with (and keep alive since) the forward one
-            const float* qp = planes + off;
+#ifdef IFD_GLOBAL_TAPS
+            const float* qp = planes_ptr + (off >> 2);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
                 tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
                 tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
                 tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
+            }
+            continue;
+#endif
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const u32x4v t0 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + 64 * mt, 0, 0);
+                const u32x4v t1 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + CH * 4 + 64 * mt, 0, 0);
+                const u32x4v t2 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + RES * CH * 4 + 64 * mt, 0, 0);
+                const u32x4v t3 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + RES * CH * 4 + CH * 4 + 64 * mt, 0, 0);
+                tap[t][0][mt] = __builtin_bit_cast(f32x4, t0);
+                tap[t][1][mt] = __builtin_bit_cast(f32x4, t1);
+                tap[t][2][mt] = __builtin_bit_cast(f32x4, t2);
+                tap[t][3][mt] = __builtin_bit_cast(f32x4, t3);
             }
         }
     };
@@ -540,18 +596,34 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    WFrag A = load_wfrag<false>(Wd, lo);         // weights of the first layer (after the gather: its registers are free now)
-    Acc2 B = load_bias(W, 0, lo);
+    // ---- fc_p on the matrix pipe: n_0 = [Wp | bp + bc_0] [x; 1]  (K = 4: one MFMA per M-tile and sub-tile) ----------
+    // The lane's B operand is component q of its point (X.w = 1 carries the bias), its A operand row 16 mt + n, column q of
+    // the [32][4] fc_p block.  (The biases of fc_c[i] are folded into the bias of the layer before: api.cpp build_dec_image.)
     Acc2 net[2];
+#ifdef IFD_FCP_VALU
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                net[t].t[mt][j] = fmaf(wp.z, geo[t].x[2], fmaf(wp.y, geo[t].x[1], fmaf(wp.x, geo[t].x[0], wp.w)));
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 xx = t ? xfb : xfa;
+                net[t].t[mt][j] = fmaf(wp.z, xx.z, fmaf(wp.y, xx.y, fmaf(wp.x, xx.x, wp.w)));
+            }
         }
+#else
+    {
+        const float ap0 = W[DEC_OFF_WP + n * 4 + q], ap1 = W[DEC_OFF_WP + (16 + n) * 4 + q];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float xq = t ? xqb : xqa;
+            net[t].t[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap0, xq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            net[t].t[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, xq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+#endif
+    WFrag A = load_wfrag<false>(Wd, lo);         // weights of the first layer (after the gather: its registers are free now)
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- forward MLP, software pipelined ---------------------------------------------------------------------
@@ -559,40 +631,39 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) {
         const float* Wl = Wd + 3 * i * W_LAYER;
-        // fc_c: a = n + fc_c(c)
-        Acc2 a0 = acc_add(B, net[0]), a1 = acc_add(B, net[1]);
+        // fc_c: a = n + fc_c(c)   (bias already inside n)
+        Acc2 a0 = net[0], a1 = net[1];
         mfma16(A, c[0], a0);                                                  // R1
         region_end<0, 0>();
         const WFrag A0 = load_wfrag<false>(Wl + W_LAYER, lo);                 // R2: prefetch fc_0
-        const Acc2 B0 = load_bias(W, 3 * i + 1, lo);
+        const Acc2 B0 = bias(3 * i + 1);
         mfma16(A, c[1], a1);
         const f32x8 af0 = flat(a0);
-        mask_a[0][i] = mask_pos_packed(af0);
+        mask_a[0][i] = mask_alive_packed(af0);
         const f32x8 ra0 = relu8(af0);
-        region_end<2, 1>();
+        region_end<TV, 1>();
         Acc2 h0 = B0;                                                          // R3
         mfma16(A0, ra0, h0);
         const f32x8 af1 = flat(a1);
-        mask_a[1][i] = mask_pos_packed(af1);
+        mask_a[1][i] = mask_alive_packed(af1);
         const f32x8 ra1 = relu8(af1);
-        region_end<2, 0>();
+        region_end<TV, 0>();
         const WFrag A1 = load_wfrag<false>(Wl + 2 * W_LAYER, lo);             // R4: prefetch fc_1
-        const Acc2 B1 = load_bias(W, 3 * i + 2, lo);
+        const Acc2 B1 = bias(3 * i + 2);
         Acc2 h1 = B0;
         mfma16(A0, ra1, h1);
         const f32x8 hf0 = flat(h0);
-        mask_h[0][i] = mask_pos_packed(hf0);
+        mask_h[0][i] = mask_alive_packed(hf0);
         const f32x8 rh0 = relu8(hf0);
-        region_end<2, 1>();
+        region_end<TV, 1>();
         Acc2 o0 = acc_add(B1, a0);                                             // R5
         mfma16(A1, rh0, o0);
         const f32x8 hf1 = flat(h1);
-        mask_h[1][i] = mask_pos_packed(hf1);
+        mask_h[1][i] = mask_alive_packed(hf1);
         const f32x8 rh1 = relu8(hf1);
-        region_end<2, 0>();
+        region_end<TV, 0>();
         if (i + 1 < NBLK) {                                                    // R6: prefetch next fc_c / first fc_1^T
             A = load_wfrag<false>(Wl + 3 * W_LAYER, lo);
-            B = load_bias(W, 3 * i + 3, lo);
         } else {
             A = load_wfrag<true>(Wl + 2 * W_LAYER, lo);
         }
@@ -613,24 +684,33 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const f32x8 nf = flat(net[t]);
+        const uint32_t mask_n = mask_alive_packed(nf);
+        const f32x8 rn = relu8(nf);
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) part = fmaf(wout[r], fmaxf(nf[r], 0.f), part);
+        for (int r = 0; r < 8; ++r) part = fmaf(wout[r], rn[r], part);
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
         const float logit = part + W[DEC_OFF_BOUT];
         float dl;
         if (MODE == MODE_OPT) {
+            // BCE-with-logits against the threshold (opt_defense.py:213-216): d/dlogit = (sigmoid - thr) / B.  The
+            // loss value itself is only reported for the last step.
             const float e = expf(-fabsf(logit));
-            bce[t] = fmaxf(logit, 0.f) - thr * logit + log1pf(e);
-            const float sig = logit >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            const float rc = __builtin_amdgcn_rcpf(1.f + e);
+            const float sig = logit >= 0.f ? rc : e * rc;
             dl = (sig - thr) * inv_lb;
+            bce[t] = want_loss ? fmaxf(logit, 0.f) - thr * logit + log1pf(e) : 0.f;
         } else {
             bce[t] = logit;
             dl = 1.f;
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) dn[t][r] = nf[r] > 0.f ? dl * wout[r] : 0.f;
+        for (int r = 0; r < 8; ++r) {
+            uint32_t keep;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(mask_n), "n"(7 - r));
+            dn[t][r] = __uint_as_float(__float_as_uint(dl * wout[r]) & keep);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -686,9 +766,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
     // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
     f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
     // packed along the channels (even / odd partial sums, added at the end): register pairs as loaded, no shuffling
-    // d pix / d x = (RES - 1) / 2 * 2 / sdiv as one constant (the reference multiplies and divides in sequence; the
-    // difference is a rounding in the last place of a gradient term)
-    const float ksc = ((0.5f * (float)(RES - 1)) * 2.f) / dc.sdiv;
     auto sample_bwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -714,8 +791,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, const
             float gix, giy;
             asm("v_add_f32 %0, %1, %2" : "=v"(gix) : "v"(pgx.x), "v"(pgx.y));
             asm("v_add_f32 %0, %1, %2" : "=v"(giy) : "v"(pgy.x), "v"(pgy.y));
-            g[t][a0] = fmaf(gg.live[a0] * ksc, gix, g[t][a0]);
-            g[t][a1] = fmaf(gg.live[a1] * ksc, giy, g[t][a1]);
+            g[t][a0] = fmaf(gg.lk[a0], gix, g[t][a0]);
+            g[t][a1] = fmaf(gg.lk[a1], giy, g[t][a1]);
         }
     };
     {
@@ -760,12 +837,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
     float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
     const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
-    unsigned long long* __restrict__ counters, int K, OptArgs A) {
+    unsigned long long* __restrict__ counters, const float* __restrict__ adam_tab, int K, OptArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
     f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
-    f32x4* X = G + MAXK;                                             // current points; X[MAXK] = far-away dummy
-    long long* F = reinterpret_cast<long long*>(X + MAXK + 1);       // fixed-point neighbour-gradient scatter
+    f32x4* X = G + MAXK;                                             // current points (x, y, z, 1); X[MAXK] = far-away dummy
+    f32x4* PIX = X + MAXK + 1;                                       // their sampling coordinates (pix_encode)
+    long long* F = reinterpret_cast<long long*>(PIX + MAXK);         // fixed-point neighbour-gradient scatter
     float* scratch = reinterpret_cast<float*>(F + 3 * MAXK);         // 128 floats
 
     const int cloud = blockIdx.x;
@@ -778,94 +856,128 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
-    AdamState ast;
-    float (&mm)[6] = ast.mm;
-    float (&vv)[6] = ast.vv;
+    // Per-thread state of the kNN / Adam phases (Adam moments, neighbour-list certificates): parked in scratch while the
+    // decoder tiles run (knn_device.h "Parking") - the tile phase owns the whole register file.
+    f32x4 park[PARK_SLOTS];
+    {
+        AdamState ast;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pt = q ? pb : pa;
+        for (int q = 0; q < 2; ++q) {
+            const int pt = q ? pb : pa;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) mm[3 * q + a] = vv[3 * q + a] = 0.f;
-        if (pt < K) {
-            X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
-            if (A.t0 > 0 && m_io != nullptr) {
+            for (int a = 0; a < 3; ++a) ast.mm[3 * q + a] = ast.vv[3 * q + a] = 0.f;
+            if (pt < K) {
+                X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 1.f};
+                PIX[pt] = pix_encode(pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], A.dc);
+                if (A.t0 > 0 && m_io != nullptr) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    mm[3 * q + a] = m_io[((size_t)cloud * K + pt) * 3 + a];
-                    vv[3 * q + a] = v_io[((size_t)cloud * K + pt) * 3 + a];
+                    for (int a = 0; a < 3; ++a) {
+                        ast.mm[3 * q + a] = m_io[((size_t)cloud * K + pt) * 3 + a];
+                        ast.vv[3 * q + a] = v_io[((size_t)cloud * K + pt) * 3 + a];
+                    }
                 }
             }
         }
+        const KnnPt k0 = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false};   // ~10 front / ~35 total hits on a flat patch
+        const int z = opaque_zero();
+        park_adam(park, z, ast);
+        park_knnpt(park, z, PARK_KNN, k0);
+        park_knnpt(park, z, PARK_KNN + 4, k0);
+        park[z + PARK_KNN + 3] = f32x4{0.f, 0.f, 0.f, 0.f};          // rep_loss_a / rep_loss_b of the last step
     }
     for (int i = tid; i < MAXK * 3; i += NW * 64) F[i] = 0;
-    if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 0.f};
+    if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 1.f};
 
     const DecConst dc = A.dc;
+    const __amdgpu_buffer_rsrc_t plr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pl), 0, CLOUD_PLANE_FLOATS * 4, 0x00020000);
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
     const int loss_batch = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : A.loss_batch;
     const float inv_lb = 1.0f / (float)loss_batch;
     const float rep_scale = A.rep_weight / ((float)loss_batch * (float)K * 5.f);
     const bool use_rep = A.rep_weight > 0.f;
-    ast.b1t = pow(0.9, (double)A.t0);
-    ast.b2t = pow(0.999, (double)A.t0);
-    float rep_loss_a = 0.f, rep_loss_b = 0.f;
-    // certified neighbour lists of the two owned points
-    uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;   // global (L2-resident)
-    uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + (pb & (MAXK - 1))) * LIST_M;
-    KnnPt ka = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false};   // ~10 front / ~35 total hits on a flat patch
-    KnnPt kb = ka;
-    uint16_t* cloud_lists = knn_lists + (size_t)cloud * MAXK * LIST_M;
+    uint16_t* cloud_lists = knn_lists + (size_t)cloud * MAXK * LIST_M;   // certified neighbour lists, global (L2-resident)
     float* dmaxbuf = scratch + 32;                                   // [2][MAX_WAVES] per-wave max |x - x0| (next step)
     float* movebuf = scratch + 64;                                   // [2][MAX_WAVES] per-wave max single-step move
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
     int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
-    KnnCounters cn;
+    unsigned int* lcnt = reinterpret_cast<unsigned int*>(scratch + 96);           // [CN_COUNT] event counters
     const KnnShared ksh = {dmaxbuf, movebuf, rebuild_flag};
     if (tid < 2) rebuild_flag[tid] = 0;
     if (tid == 0) *tile_ctr = 0;
+    if (tid < CN_COUNT) lcnt[tid] = 0u;
     if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
     __syncthreads();
+#ifdef IFD_PROF
+    KnnCounters cnp{lcnt, lane};
+#endif
 
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
-        long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
-        // Work of one step: the kNN / repulsion of the points each wave owns, then ntiles decoder tiles pulled from an
-        // LDS counter.  Every wave runs its kNN phase FIRST, all at the same time (quota = 0 tiles before it): pairing
-        // a VALU-only kNN wave with an MFMA-heavy tile wave on a SIMD - the first design, quota = ntiles / 16 for
-        // waves 0-3 - buys nothing, because MFMA and VALU issue do not overlap on gfx950, and starves the VALU wave
-        // (measured: 249 -> 233 us per step).  The two-pass loop shape is kept on purpose: hipcc's code for the flat
-        // form (kNN, then one tile loop) measured 239-243 us.
-        const int quota = 0;
-#pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase) {
-            if (phase == 1 && wave < OWN_WAVES && use_rep) {
-                knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb,
-                          ksh, rc, rep_loss_a, rep_loss_b, gca, gcb, cn);
-            }
-            PROF_T0();
-            // decoder tiles: pass 0 = up to `quota` tiles before the kNN, pass 1 = until the step's tiles run out
-#pragma unroll 1
-            for (int n = 0; phase == 1 || n < quota; ++n) {
-                int tile = 0;
-                if (lane == 0) tile = atomicAdd(tile_ctr, 1);
-                tile = __shfl(tile, 0);
-                if (tile >= ntiles) break;
-                const int ia = tile * 32 + (lane & 15), ib = ia + 16;    // two 16-point sub-tiles, software-pipelined
-                const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
-                float bce[2], dx[2][3];
-                decoder_tile3<MODE_OPT>(W, pl, X[tpa], X[tpb], lane, dc, A.threshold, inv_lb, bce, dx);
-                if (lane < 16) {
-                    if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
-                    if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
-                }
-            }
-            PROF_ACC(pc_tiles);
+        const bool want_loss = last && loss_out != nullptr;
+        // Everything a phase derives from the thread index (LDS addresses of candidates, list pointers, tile lanes) is
+        // re-derived from an opaque copy once per step: left alone, LICM hoists those cheap invariants out of the
+        // 501-step loop and they end up in scratch, reloaded one by one inside the phases.
+        int tid_s = tid;
+        asm volatile("" : "+v"(tid_s));
+        const int lane = tid_s & 63, wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
+        const bool owner = tid_s < OPT_THREADS;
+        const int pa = owner ? tid_s : MAXK, pb = owner ? tid_s + OPT_THREADS : MAXK;
+#ifdef IFD_PROF
+        KnnCounters& cn = cnp;
+#else
+        KnnCounters cn{lcnt, lane};
+#endif
+        // ---- kNN + repulsion of the points this wave owns (all waves at the same time: a VALU-only wave next to an
+        //      MFMA-heavy tile wave on a SIMD is starved, f32 MFMA and VALU issue do not overlap on gfx950) -------------
+        if (wave < OWN_WAVES && use_rep) {
+            KnnPt ka, kb;
+            float rep_loss_a, rep_loss_b;
+            const int z = opaque_zero();
+            unpark_knnpt(park, z, PARK_KNN, ka);
+            unpark_knnpt(park, z, PARK_KNN + 4, kb);
+            uint16_t* La = cloud_lists + (size_t)(pa & (MAXK - 1)) * LIST_M;
+            uint16_t* Lb = cloud_lists + (size_t)(pb & (MAXK - 1)) * LIST_M;
+            knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb,
+                      ksh, rc, rep_loss_a, rep_loss_b, cn);
+            const int z2 = opaque_zero();
+            park_knnpt(park, z2, PARK_KNN, ka);
+            park_knnpt(park, z2, PARK_KNN + 4, kb);
+            if (want_loss) park[z2 + PARK_KNN + 3] = f32x4{rep_loss_a, rep_loss_b, 0.f, 0.f};
         }
+        PROF_T0();
+        // ---- decoder tiles, pulled from an LDS counter until the step's tiles run out -----------------------------------
+#pragma unroll 1
+        for (;;) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(tile_ctr, 1);
+            tile = __shfl(tile, 0);
+            if (tile >= ntiles) break;
+            const int ia = tile * 32 + (lane & 15), ib = ia + 16;    // two 16-point sub-tiles, software-pipelined
+            const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
+            float bce[2], dx[2][3];
+            const float* Xf = reinterpret_cast<const float*>(X) + (lane >> 4);      // component q of the point: fc_p's B operand
+            decoder_tile3<MODE_OPT>(W, plr, pl, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], X[tpa], X[tpb], lane, dc,
+                                    A.threshold, inv_lb, want_loss, bce, dx);
+            if (lane < 16) {
+                if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
+                if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
+            }
+        }
+        PROF_ACC(pc_tiles);
+        // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------
+        AdamState ast;
+        KnnPt ka, kb;
+        const int z3 = opaque_zero();
+        unpark_adam(park, z3, ast);
+        unpark_knnpt(park, z3, PARK_KNN, ka);
+        unpark_knnpt(park, z3, PARK_KNN + 4, kb);
+        const f32x4 rl = park[z3 + PARK_KNN + 3];
+        const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
         __syncthreads();
         PROF_ACC(pc_wait);
-        if (last && loss_out != nullptr) {   // losses at the pre-update points of the last step
+        if (want_loss) {   // losses at the pre-update points of the last step
             float occ = (pa < K ? G[pa].w : 0.f) + (pb < K ? G[pb].w : 0.f);
-            float rep = (pa < K ? rep_loss_a : 0.f) + (pb < K ? rep_loss_b : 0.f);
+            float rep = (pa < K ? rl.x : 0.f) + (pb < K ? rl.y : 0.f);
             occ = wave_sum(occ);
             rep = wave_sum(rep);
             if (lane == 0) { scratch[wave] = occ; scratch[MAX_WAVES + wave] = rep; }
@@ -877,35 +989,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
         }
-        adam_phase(X, G, F, K, pa, pb, wave, lane, step, A.lr, rep_scale, gca, gcb, ast, ka, kb, ksh);
+        adam_phase(X, G, F, K, pa, pb, wave, lane, step, step_size, bc2, rep_scale, ast, ka, kb, ksh);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {        // sampling coordinates of the moved points, for the next step's decoder tiles
+            const int pt = q ? pb : pa;
+            if (pt < K) { const f32x4 x = X[pt]; PIX[pt] = pix_encode(x.x, x.y, x.z, dc); }
+        }
+        park_adam(park, opaque_zero(), ast);
         if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
         __syncthreads();
         PROF_ACC(pc_adam);
     }
 
-    if (counters != nullptr && lane == 0) {
-        atomicAdd(counters + 0, (unsigned long long)cn.n_rebuild);   // wave-level list rebuilds
-        atomicAdd(counters + 1, (unsigned long long)cn.n_brute);     // wave-level certificate failures (exact scans)
-        atomicAdd(counters + 2, (unsigned long long)cn.n_pass);      // extra rebuild work: exact scans for radii + overflow re-passes
-        atomicAdd(counters + 4, (unsigned long long)cn.n_tier2);     // wave-steps that had to evaluate the back ring
-        atomicAdd(counters + 5, (unsigned long long)cn.n_exact);     // wave-steps on the exact insertion path (last step, near-ties)
-        atomicAdd(counters + 6, (unsigned long long)cn.n_refresh);   // wave-steps with individual list refreshes
-        atomicAdd(counters + 7, (unsigned long long)cn.n_targets);   // lists built (whole-cloud rebuilds + individual refreshes)
+    if (counters != nullptr) {
+        if (tid < CN_COUNT) {
+            constexpr int SLOT[CN_COUNT] = {0, 1, 2, 4, 5, 6, 7};     // rebuilds, exact scans, extra passes, ring evaluations,
+            atomicAdd(counters + SLOT[tid], (unsigned long long)lcnt[tid]);   // exact-path evaluations, refreshes, lists built
+        }
         if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
 #ifdef IFD_PROF
         if (tid == 0) {
             const unsigned long long cyc = __builtin_readcyclecounter() - t_begin;
             atomicMax(counters + 14, cyc);
-            atomicMax(counters + 13, (unsigned long long)cn.n_rebuild << 32);
+            atomicMax(counters + 13, (unsigned long long)lcnt[CN_REBUILD] << 32);
             atomicAdd(counters + 15, cyc);
         }
-        if (cloud == 0) {
-            atomicAdd(counters + 8, cn.pc_build); atomicAdd(counters + 9, cn.pc_eval); atomicAdd(counters + 10, cn.pc_rep);
-            atomicAdd(counters + 11, cn.pc_tiles); atomicAdd(counters + 12, cn.pc_wait); atomicAdd(counters + 13, cn.pc_adam);
+        if (cloud == 0 && lane == 0) {
+            atomicAdd(counters + 8, cnp.pc_build); atomicAdd(counters + 9, cnp.pc_eval); atomicAdd(counters + 10, cnp.pc_rep);
+            atomicAdd(counters + 11, cnp.pc_tiles); atomicAdd(counters + 12, cnp.pc_wait); atomicAdd(counters + 13, cnp.pc_adam);
         }
 #endif
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
+    AdamState ast;
+    unpark_adam(park, opaque_zero(), ast);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int pt = q ? pb : pa;
@@ -915,8 +1032,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             if (m_io != nullptr) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    m_io[((size_t)cloud * K + pt) * 3 + a] = mm[3 * q + a];
-                    v_io[((size_t)cloud * K + pt) * 3 + a] = vv[3 * q + a];
+                    m_io[((size_t)cloud * K + pt) * 3 + a] = ast.mm[3 * q + a];
+                    v_io[((size_t)cloud * K + pt) * 3 + a] = ast.vv[3 * q + a];
                 }
             }
         }
@@ -1022,7 +1139,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 2 + 16 + MAXK * 3 * 8 + 128 * 4;   // 125,728 B
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 3 * 8 + 128 * 4;   // 142,112 B
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;
 constexpr size_t NRM_LDS = MAXK * 16 + 64;
@@ -1041,9 +1158,27 @@ hipError_t configure_optimize_kernels() {
 
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
                            float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
-                           unsigned long long* counters, int B, int K, const OptArgs& a, hipStream_t s) {
+                           unsigned long long* counters, const float* adam_tab, int B, int K, const OptArgs& a,
+                           hipStream_t s) {
     hipLaunchKernelGGL((optimize_kernel<8>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                       loss_batch_per_cloud, knn_lists, counters, K, a);
+                       loss_batch_per_cloud, knn_lists, counters, adam_tab, K, a);
+    return hipGetLastError();
+}
+
+// Bias corrections of torch.optim.Adam for steps t0 + 1 ... t0 + steps (torch/optim/adam.py _single_tensor_adam:
+// bias_correction1 = 1 - beta1 ** step, step_size = lr / bias_correction1, bias_correction2_sqrt = sqrt(1 - beta2 ** step),
+// Python doubles there, doubles here), rounded to float where torch hands them to its float kernels.
+__global__ void adam_table_kernel(float* __restrict__ tab, int t0, int steps, double lr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= steps) return;
+    const double t = (double)(t0 + i + 1);
+    tab[2 * i] = (float)(lr / (1.0 - pow(0.9, t)));
+    tab[2 * i + 1] = (float)sqrt(1.0 - pow(0.999, t));
+}
+
+hipError_t launch_adam_table(float* tab, int t0, int steps, float lr, hipStream_t s) {
+    if (steps <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adam_table_kernel, dim3((steps + 255) / 256), dim3(256), 0, s, tab, t0, steps, (double)lr);
     return hipGetLastError();
 }
 
