@@ -87,13 +87,20 @@ struct KnnCounters {
     __device__ __forceinline__ void bump(int which, unsigned int n = 1u) const {
         if (lane == 0) atomicAdd(lds + which, n);
     }
-#ifdef IFD_PROF      // cycle accounting (diagnostic builds only)
-    unsigned long long pc_build = 0, pc_eval = 0, pc_rep = 0, pc_tiles = 0, pc_wait = 0, pc_adam = 0, pc_t = 0;
+#ifdef IFD_PROF      // cycle accounting (diagnostic builds only): per-wave accumulators in LDS, no registers held
+    unsigned long long* pc = nullptr;  // [PC_COUNT] of this wave; pc[PC_T] = time stamp of the last marker
 #endif
 };
+enum { PC_BUILD = 0, PC_EVAL, PC_REP, PC_TILES, PC_WAIT, PC_ADAM, PC_T, PC_COUNT = 8 };
 #ifdef IFD_PROF
-#define PROF_T0() cn.pc_t = __builtin_readcyclecounter()
-#define PROF_ACC(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); cn.v += n_ - cn.pc_t; cn.pc_t = n_; } while (0)
+#define PROF_T0() do { if (cn.lane == 0 && cn.pc) cn.pc[PC_T] = __builtin_readcyclecounter(); } while (0)
+#define PROF_ACC(v) do { if (cn.lane == 0 && cn.pc) { const unsigned long long n_ = __builtin_readcyclecounter(); cn.pc[v] += n_ - cn.pc[PC_T]; cn.pc[PC_T] = n_; } } while (0)
+#define pc_build PC_BUILD
+#define pc_eval PC_EVAL
+#define pc_rep PC_REP
+#define pc_tiles PC_TILES
+#define pc_wait PC_WAIT
+#define pc_adam PC_ADAM
 #else
 #define PROF_T0()
 #define PROF_ACC(v)

@@ -351,19 +351,41 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 // The taps are gathered one plane at a time and re-gathered for the backward pass (L1/L2 hits): holding them
 // for two sub-tiles would need 192 VGPRs.
 // ---------------------------------------------------------------------------------------------
-// ReLU masks of the optimiser tile.  One v_alignbit per value shifts the SIGN bit of the pre-activation into the mask
-// word (value r -> bit 7 - r), the word is inverted once, and the backward pass applies it with v_bfe_i32 (bit -> 0 / -1)
-// + v_and.  "Alive" therefore means sign bit clear: v > 0 or v == +0.0 - torch's threshold_backward uses v > 0, so the
-// two differ only for a pre-activation that is exactly +0.0 (forward values are identical; the one structural case,
-// a zero bias under an all-dead input, sits under a dead outer mask).  Integer and bit-field instructions cost ~6
-// SIMD cycles each next to the f32 MFMAs (scripts/valu_rates.hip), v_and / v_add / v_fma ~4.5: the earlier exact-at-+0
-// form (v_max, v_add -1, v_alignbit | v_bfe, v_bfi) was 29 cycles per value, this one is 24.
-__device__ __forceinline__ uint32_t mask_alive_packed(const f32x8& v) {
-    uint32_t m = 0;
+// ReLU masks of the optimiser tile.  One v_alignbyte per value shifts the top byte of the pre-activation (sign bit
+// first) into a mask word, four values per word (value r -> byte 3 - r of word r / 4); the words are inverted once, and
+// the backward pass applies a mask with ONE v_and_b32_sdwa per value (the sign-extended byte: all ones where the sign
+// bit was clear).  "Alive" therefore means sign bit clear: v > 0 or v == +0.0 - torch's threshold_backward uses v > 0, so
+// the two differ only for a pre-activation that is exactly +0.0 (forward values are identical; the one structural case,
+// a zero bias under an all-dead input, sits under a dead outer mask).  Integer / bit-field / SDWA instructions cost ~6
+// SIMD cycles each next to the f32 MFMAs (scripts/valu_rates.hip): round 1's exact-at-+0 form (v_max, v_add -1,
+// v_alignbit | v_bfe, v_bfi) was 29 cycles per value, bit masks through v_alignbit | v_bfe + v_and 24, this one 20.
+struct Mask8 {
+    uint32_t w[2];
+};
+// v: pre-activations straight out of the MFMAs; rv: relu(v) as the compiler computed it.  The inline asm lists rv as an
+// (unused) input so that it is ordered behind the compiler's own first read of v - the compiler pads MFMA -> VALU
+// read-after-write hazards for its own instructions, not for inline asm.
+template <int BYTE>
+__device__ __forceinline__ void put_sign_byte(uint32_t& x, float v, float rv, int c31) {
+    if (BYTE == 0) asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(c31), "v"(v), "v"(rv));
+    if (BYTE == 1) asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(c31), "v"(v), "v"(rv));
+    if (BYTE == 2) asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(c31), "v"(v), "v"(rv));
+    if (BYTE == 3) asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(c31), "v"(v), "v"(rv));
+}
+__device__ __forceinline__ Mask8 mask_alive_packed(const f32x8& v, const f32x8& rv, int c31) {
+    Mask8 m;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(v[r]), 31);
-    m = ~m;
-    asm volatile("" : "+v"(m));
+    for (int h = 0; h < 2; ++h) {
+        uint32_t x;                                  // byte 3 - r of word h: 0xff where value 4 h + r has its sign bit set
+        asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+            : "=v"(x) : "v"(c31), "v"(v[4 * h + 0]), "v"(rv[4 * h + 0]));
+        put_sign_byte<2>(x, v[4 * h + 1], rv[4 * h + 1], c31);
+        put_sign_byte<1>(x, v[4 * h + 2], rv[4 * h + 2], c31);
+        put_sign_byte<0>(x, v[4 * h + 3], rv[4 * h + 3], c31);
+        x = ~x;
+        asm volatile("" : "+v"(x));
+        m.w[h] = x;
+    }
     return m;
 }
 
@@ -442,16 +464,23 @@ __device__ __forceinline__ Acc2 acc_zero() {
     r.t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     return r;
 }
-__device__ __forceinline__ f32x8 masked(const Acc2& z, uint32_t alive) {
-    f32x8 v = flat(z);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        uint32_t keep;                                            // v_bfe_i32: 0 / -1
-        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(alive), "n"(7 - r));
-        v[r] = __uint_as_float(__float_as_uint(v[r]) & keep);
-    }
+// z & (sign-extended mask byte): written so that hipcc's SDWA peephole folds the byte extraction into the v_and
+// (v_and_b32_sdwa ... src0_sel:BYTE_k with sext) - one instruction per value, and the compiler keeps track of the
+// MFMA -> VALU hazard of z itself.
+template <int BYTE>
+__device__ __forceinline__ float keep_alive(float z, uint32_t word) {
+    const int keep = (int)(int8_t)(word >> (8 * BYTE));
+    return __uint_as_float(__float_as_uint(z) & (uint32_t)keep);
+}
+__device__ __forceinline__ f32x8 masked(const f32x8& z, const Mask8& m) {
+    f32x8 v;
+    v[0] = keep_alive<3>(z[0], m.w[0]); v[1] = keep_alive<2>(z[1], m.w[0]);
+    v[2] = keep_alive<1>(z[2], m.w[0]); v[3] = keep_alive<0>(z[3], m.w[0]);
+    v[4] = keep_alive<3>(z[4], m.w[1]); v[5] = keep_alive<2>(z[5], m.w[1]);
+    v[6] = keep_alive<1>(z[6], m.w[1]); v[7] = keep_alive<0>(z[7], m.w[1]);
     return v;
 }
+__device__ __forceinline__ f32x8 masked(const Acc2& z, const Mask8& m) { return masked(flat(z), m); }
 
 // ---- sampling coordinates, once per point and step ---------------------------------------------------------------
 // The owner thread of a point turns its coordinates into the three pixel coordinates of grid_sample (pixel_coord above:
@@ -573,7 +602,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {      // (one fma chain over all 12 taps measured +2.6 %)
                     float s = tap[t][0][mt][j] * wnw;
                     s = fmaf(tap[t][1][mt][j], wne, s);
                     s = fmaf(tap[t][2][mt][j], wsw, s);
@@ -627,7 +656,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- forward MLP, software pipelined ---------------------------------------------------------------------
-    uint32_t mask_a[2][NBLK], mask_h[2][NBLK];
+    Mask8 mask_a[2][NBLK], mask_h[2][NBLK];
+    int c31 = 31;                                  // shift count of the sign-byte extraction (an SDWA operand must be a register)
+    asm volatile("" : "+v"(c31));
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) {
         const float* Wl = Wd + 3 * i * W_LAYER;
@@ -639,28 +670,28 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         const Acc2 B0 = bias(3 * i + 1);
         mfma16(A, c[1], a1);
         const f32x8 af0 = flat(a0);
-        mask_a[0][i] = mask_alive_packed(af0);
         const f32x8 ra0 = relu8(af0);
+        mask_a[0][i] = mask_alive_packed(af0, ra0, c31);
         region_end<TV, 1>();
         Acc2 h0 = B0;                                                          // R3
         mfma16(A0, ra0, h0);
         const f32x8 af1 = flat(a1);
-        mask_a[1][i] = mask_alive_packed(af1);
         const f32x8 ra1 = relu8(af1);
+        mask_a[1][i] = mask_alive_packed(af1, ra1, c31);
         region_end<TV, 0>();
         const WFrag A1 = load_wfrag<false>(Wl + 2 * W_LAYER, lo);             // R4: prefetch fc_1
         const Acc2 B1 = bias(3 * i + 2);
         Acc2 h1 = B0;
         mfma16(A0, ra1, h1);
         const f32x8 hf0 = flat(h0);
-        mask_h[0][i] = mask_alive_packed(hf0);
         const f32x8 rh0 = relu8(hf0);
+        mask_h[0][i] = mask_alive_packed(hf0, rh0, c31);
         region_end<TV, 1>();
         Acc2 o0 = acc_add(B1, a0);                                             // R5
         mfma16(A1, rh0, o0);
         const f32x8 hf1 = flat(h1);
-        mask_h[1][i] = mask_alive_packed(hf1);
         const f32x8 rh1 = relu8(hf1);
+        mask_h[1][i] = mask_alive_packed(hf1, rh1, c31);
         region_end<TV, 0>();
         if (i + 1 < NBLK) {                                                    // R6: prefetch next fc_c / first fc_1^T
             A = load_wfrag<false>(Wl + 3 * W_LAYER, lo);
@@ -684,8 +715,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const f32x8 nf = flat(net[t]);
-        const uint32_t mask_n = mask_alive_packed(nf);
         const f32x8 rn = relu8(nf);
+        const Mask8 mask_n = mask_alive_packed(nf, rn, c31);
         float part = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) part = fmaf(wout[r], rn[r], part);
@@ -705,11 +736,11 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             bce[t] = logit;
             dl = 1.f;
         }
+        {
+            f32x8 dw;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint32_t keep;
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(mask_n), "n"(7 - r));
-            dn[t][r] = __uint_as_float(__float_as_uint(dl * wout[r]) & keep);
+            for (int r = 0; r < 8; ++r) dw[r] = dl * wout[r];
+            dn[t] = masked(dw, mask_n);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -908,7 +939,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
     __syncthreads();
 #ifdef IFD_PROF
-    KnnCounters cnp{lcnt, lane};
+    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(F + 3 * MAXK) + 64;   // [NW][PC_COUNT] behind `scratch`
+    if (tid < NW * PC_COUNT) lprof[tid] = 0ull;
+    __syncthreads();
 #endif
 
     for (int step = 0; step < A.steps; ++step) {
@@ -923,7 +956,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         const bool owner = tid_s < OPT_THREADS;
         const int pa = owner ? tid_s : MAXK, pb = owner ? tid_s + OPT_THREADS : MAXK;
 #ifdef IFD_PROF
-        KnnCounters& cn = cnp;
+        KnnCounters cn{lcnt, lane, lprof + wave * PC_COUNT};
 #else
         KnnCounters cn{lcnt, lane};
 #endif
@@ -1014,10 +1047,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             atomicMax(counters + 13, (unsigned long long)lcnt[CN_REBUILD] << 32);
             atomicAdd(counters + 15, cyc);
         }
-        if (cloud == 0 && lane == 0) {
-            atomicAdd(counters + 8, cnp.pc_build); atomicAdd(counters + 9, cnp.pc_eval); atomicAdd(counters + 10, cnp.pc_rep);
-            atomicAdd(counters + 11, cnp.pc_tiles); atomicAdd(counters + 12, cnp.pc_wait); atomicAdd(counters + 13, cnp.pc_adam);
-        }
+        if (cloud == 0 && tid < NW * PC_COUNT && (tid % PC_COUNT) < 6) atomicAdd(counters + 8 + tid % PC_COUNT, lprof[tid]);
 #endif
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
@@ -1139,7 +1169,11 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+#ifdef IFD_PROF
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 3 * 8 + 128 * 4 + 8 * 8 * 8;
+#else
 constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 3 * 8 + 128 * 4;   // 142,112 B
+#endif
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;
 constexpr size_t NRM_LDS = MAXK * 16 + 64;
