@@ -14,6 +14,9 @@
 
 #include "ifd_internal.h"
 
+// device-side size of the counter buffer: the IFD_N_COUNTERS public slots + the per-wave time stamps of -DIFD_TRACE builds
+constexpr int N_COUNTERS_DEV = IFD_N_COUNTERS + 8 * 32;
+
 using namespace ifd;
 
 namespace {
@@ -316,8 +319,8 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         std::vector<float> img = build_dec_image(ctx->w.data());
         e = hipMemcpy(ctx->d_dec_img, img.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), IFD_N_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_DEV * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_w), n_weights * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w, ctx->w.data(), n_weights * sizeof(float), hipMemcpyHostToDevice);
     {
@@ -487,14 +490,14 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
 
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
     if (!ctx || !out_host || n < 1) return IFD_ERR_ARG;
-    unsigned long long tmp[IFD_N_COUNTERS] = {0};
+    unsigned long long tmp[N_COUNTERS_DEV] = {0};
     hipError_t e = hipMemcpy(tmp, ctx->d_counters, sizeof(tmp), hipMemcpyDeviceToHost);   // synchronises
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_get_counters", e);
     if (ctx->model == IFD_MODEL_ONET) {   // host-side tallies of the last ifd_onet_mesh_sample
         tmp[8] = ctx->mesh_points;
         tmp[9] = ctx->mesh_rounds;
     }
-    for (int i = 0; i < n; ++i) out_host[i] = i < IFD_N_COUNTERS ? tmp[i] : 0;
+    for (int i = 0; i < n; ++i) out_host[i] = i < N_COUNTERS_DEV ? tmp[i] : 0;   // slots >= IFD_N_COUNTERS: wave trace (diagnostic builds)
     return IFD_OK;
 }
 
@@ -572,8 +575,8 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     upload(&ctx->d_w, dev);
     upload(&ctx->d_onet_img, img);
     upload(&ctx->d_onet_small, small);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), IFD_N_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_DEV * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long));
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e == hipSuccess) e = configure_onet_kernels();

@@ -87,24 +87,29 @@ struct KnnCounters {
     __device__ __forceinline__ void bump(int which, unsigned int n = 1u) const {
         if (lane == 0) atomicAdd(lds + which, n);
     }
-#ifdef IFD_PROF      // cycle accounting (diagnostic builds only): per-wave accumulators in LDS, no registers held
-    unsigned long long* pc = nullptr;  // [PC_COUNT] of this wave; pc[PC_T] = time stamp of the last marker
+#if defined(IFD_PROF) || defined(IFD_TRACE)   // diagnostic builds only
+    // IFD_PROF: per-wave cycle accumulators in LDS.  IFD_TRACE: time stamps of ONE step of cloud 0 in global memory
+    // (null on every other step / cloud).  pc[PC_T] = time stamp of the last marker.
+    unsigned long long* pc = nullptr;
 #endif
 };
-enum { PC_BUILD = 0, PC_EVAL, PC_REP, PC_TILES, PC_WAIT, PC_ADAM, PC_T, PC_COUNT = 8 };
-#ifdef IFD_PROF
+enum { PC_BUILD = 0, PC_EVAL, PC_REP, PC_TILES, PC_WAIT, PC_ADAM, PC_T, PC_KNN0, PC_TILE0, PC_COUNT = 8 };
+#if defined(IFD_PROF)
 #define PROF_T0() do { if (cn.lane == 0 && cn.pc) cn.pc[PC_T] = __builtin_readcyclecounter(); } while (0)
 #define PROF_ACC(v) do { if (cn.lane == 0 && cn.pc) { const unsigned long long n_ = __builtin_readcyclecounter(); cn.pc[v] += n_ - cn.pc[PC_T]; cn.pc[PC_T] = n_; } } while (0)
+#elif defined(IFD_TRACE)
+#define PROF_T0() do { if (cn.lane == 0 && cn.pc) cn.pc[PC_T] = __builtin_readcyclecounter(); } while (0)
+#define PROF_ACC(v) do { if (cn.lane == 0 && cn.pc) cn.pc[v] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROF_T0()
+#define PROF_ACC(v)
+#endif
 #define pc_build PC_BUILD
 #define pc_eval PC_EVAL
 #define pc_rep PC_REP
 #define pc_tiles PC_TILES
 #define pc_wait PC_WAIT
 #define pc_adam PC_ADAM
-#else
-#define PROF_T0()
-#define PROF_ACC(v)
-#endif
 
 // 5 nearest of points ia / ib among entries [E0, E1) of their lists, continuing the running top-5 in ta / tb.
 // The two independent insertion chains are interleaved for ILP.  Entries >= cnt are ignored.
@@ -474,23 +479,43 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
     }
 }
 
+// Fixed-point accumulator of the repulsion gradient in LDS (optimiser kernels).  The neighbour -> point scatter of
+// index_points' backward (repulsion_loss.py:43-47) is the one place where many threads add into the same point; LDS
+// float atomics would make the sum depend on their order.  Integer sums do not: every term is rounded to a multiple of
+// 2^-23 (its magnitude is bounded by ~7: |d loss / d d| <= w (1 + (r - d) 2 d / h^2)), x and y share one 64-bit word (x in
+// the high half; the halves' sums separate exactly as long as each stays inside 32 bits: |sum| < 256), z has a 32-bit
+// word.  12 bytes of atomics per term instead of 24 (the phase is bound by LDS atomic throughput, not by arithmetic), 3
+// conversion instructions per component instead of 11, 12 KB of LDS instead of 24.
+struct RepAcc {
+    long long* xy;       // [MAXK]
+    int* z;              // [MAXK]
+};
+constexpr float FIX32_SCALE = 8388608.0f;            // 2^23
+constexpr float FIX32_INV = 1.0f / 8388608.0f;
+__device__ __forceinline__ int fix32(float g) { return (int)rintf(g * FIX32_SCALE); }      // v_mul, v_rndne, v_cvt_i32 (saturating)
+__device__ __forceinline__ long long pack_xy(int x, int y) { return (long long)(((unsigned long long)(unsigned int)x << 32)) + (long long)y; }
+__device__ __forceinline__ void unpack_xy(long long s, int& x, int& y) {
+    y = (int)(unsigned int)(unsigned long long)s;
+    x = (int)((s - (long long)y) >> 32);
+}
+
 // The two owned points together (optimiser): one instruction stream with the two independent chains interleaved -
 // two rep_point calls under separate `if (p < K)` branches cannot overlap their LDS / sqrt / exp / divide latencies.
 // The centre's own share (minus what its five neighbours receive) goes into F with the same fixed-point atomics: integer
 // addition commutes, so F[i] ends up as the same sum whatever the order, and no register has to carry it to the Adam phase.
-__device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, long long* __restrict__ F, int K, int pa, int pb,
+__device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
                                            const Top5& ta, const Top5& tb, const RepConst rc, float& loss_a,
                                            float& loss_b) {
     const bool va = pa < K, vb = pb < K;
     const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
     const int ia[5] = {ta.i0, ta.i1, ta.i2, ta.i3, ta.i4}, ib[5] = {tb.i0, tb.i1, tb.i2, tb.i3, tb.i4};
     float la = 0.f, lb = 0.f;
-    long long gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
+    int gca[3] = {0, 0, 0}, gcb[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int ja = va ? ia[k] : 0, jb = vb ? ib[k] : 0;
         const f32x4 qa = X[ja], qb = X[jb];
-        long long f[2][3];
+        int f[2][3];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4 xi = s ? xb : xa, xj = s ? qb : qa;
@@ -503,32 +528,28 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, long lon
             (s ? lb : la) += (rc.radius - d) * w;
             const float dd = -w - (rc.radius - d) * w * (2.f * q / rc.h);
             const float coef = d2raw > rc.eps ? dd / d : 0.f;
-            f[s][0] = __float2ll_rn(coef * ex * FIX_SCALE);
-            f[s][1] = __float2ll_rn(coef * ey * FIX_SCALE);
-            f[s][2] = __float2ll_rn(coef * ez * FIX_SCALE);
+            f[s][0] = fix32(coef * ex);
+            f[s][1] = fix32(coef * ey);
+            f[s][2] = fix32(coef * ez);
         }
         if (va) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                gca[a] -= f[0][a];
-                atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * ja + a), (unsigned long long)f[0][a]);
-            }
+            gca[0] -= f[0][0]; gca[1] -= f[0][1]; gca[2] -= f[0][2];
+            atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + ja), (unsigned long long)pack_xy(f[0][0], f[0][1]));
+            atomicAdd(F.z + ja, f[0][2]);
         }
         if (vb) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                gcb[a] -= f[1][a];
-                atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * jb + a), (unsigned long long)f[1][a]);
-            }
+            gcb[0] -= f[1][0]; gcb[1] -= f[1][1]; gcb[2] -= f[1][2];
+            atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + jb), (unsigned long long)pack_xy(f[1][0], f[1][1]));
+            atomicAdd(F.z + jb, f[1][2]);
         }
     }
     if (va) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * pa + a), (unsigned long long)gca[a]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + pa), (unsigned long long)pack_xy(gca[0], gca[1]));
+        atomicAdd(F.z + pa, gca[2]);
     }
     if (vb) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) atomicAdd(reinterpret_cast<unsigned long long*>(F + 3 * pb + a), (unsigned long long)gcb[a]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + pb), (unsigned long long)pack_xy(gcb[0], gcb[1]));
+        atomicAdd(F.z + pb, gcb[2]);
     }
     loss_a = la;
     loss_b = lb;
@@ -602,7 +623,7 @@ struct KnnShared {
 
 // kNN + repulsion of the two points (pa, pb) this lane owns, for one optimiser step (all lanes of an owner wave call
 // it together).  Leaves the loss terms in rep_loss_a/b and scatters the neighbour AND centre gradients into F (fixed point).
-__device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long* __restrict__ F, int K, int pa, int pb,
+__device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
                                           int wave, int lane, int step, bool last, bool scan_every_step,
                                           const uint16_t* La, const uint16_t* Lb, uint16_t* cloud_lists, KnnPt& ka,
                                           KnnPt& kb, const KnnShared& sh, const RepConst rc, float& rep_loss_a,
@@ -701,16 +722,24 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, long long
                 soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
                 soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
             }
-            const bool amb = (pa < K && !fail_a && keys6_ambiguous(qa)) || (pb < K && !fail_b && keys6_ambiguous(qb));
-            if (__any(amb)) {
-                exact = true;
-            } else {
-                keys6_to_top5(qa, ta);
-                keys6_to_top5(qb, tb);
-                if (__builtin_expect(__any(fail_a || fail_b), 0)) {       // certificate failed: exact query for those points, this step
-                    cn.bump(CN_BRUTE);
-                    knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
-                }
+            // A near-tie between the 5th and 6th key (equal above the index bits: ~10 % of the wave-steps have one
+            // somewhere among their 128 points) is settled for THAT point by the exact wave-cooperative query below
+            // (~2 k cycles) - re-running the whole wave on the exact insertion path cost ~70 k cycles each time.
+#ifdef IFD_NO_AMB_RESOLVE
+            const bool amb_any = (pa < K && !fail_a && keys6_ambiguous(qa)) || (pb < K && !fail_b && keys6_ambiguous(qb));
+            if (__any(amb_any)) exact = true;
+            const bool amb_a = false, amb_b = false;
+            if (!exact) {
+#else
+            const bool amb_a = pa < K && !fail_a && keys6_ambiguous(qa), amb_b = pb < K && !fail_b && keys6_ambiguous(qb);
+            {
+#endif
+            keys6_to_top5(qa, ta);
+            keys6_to_top5(qb, tb);
+            if (__any(amb_a || amb_b)) cn.bump(CN_EXACT);
+            if (__builtin_expect(__any(fail_a || fail_b), 0)) cn.bump(CN_BRUTE);      // certificate failed
+            if (__any(fail_a || fail_b || amb_a || amb_b))     // exact query for those points, this step
+                knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a || amb_a, fail_b || amb_b, ta, tb);
             }
         }
         if (exact) {
@@ -759,7 +788,7 @@ struct AdamState {
 // and bc2 = sqrt(1 - beta2^t) come from a per-step table the host computes in double like torch's Python scalars
 // (adam_table in api.cpp).  Also reduces this wave's displacement / step-length maxima for the neighbour-list
 // certificates of the next step.
-__device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* __restrict__ G, long long* __restrict__ F,
+__device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* __restrict__ G, const RepAcc F,
                                            int K, int pa, int pb, int wave, int lane, int step, float step_size,
                                            float bc2, float rep_scale, AdamState& st, const KnnPt& ka, const KnnPt& kb,
                                            const KnnShared& sh) {
@@ -779,16 +808,22 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             const float gocc[3] = {go.x, go.y, go.z};
             float xs[3] = {x.x, x.y, x.z};
             float msq = 0.f;
+            int fi[3];
+            unpack_xy(F.xy[pt], fi[0], fi[1]);
+            fi[2] = F.z[pt];
+            F.xy[pt] = 0;
+            F.z[pt] = 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float gn = __ll2float_rn(F[3 * pt + a]) * FIX_INV;
-                F[3 * pt + a] = 0;
+                const float gn = (float)fi[a] * FIX32_INV;
                 const float gr = gn * rep_scale;
                 const float g = gocc[a] + gr;
                 float& mr = mm[3 * q + a];
                 float& vr = vv[3 * q + a];
                 mr = mr + (g - mr) * (1.f - 0.9f);
                 vr = vr * 0.999f + (1.f - 0.999f) * g * g;
+                // sqrt(v) / bc2 + eps and m / denom through v_sqrt_f32 / v_rcp_f32 (1 ulp each): the update differs from
+                // torch's by ~1e-7 of ITS size (~1e-10 absolute), the moments themselves are exact
                 const float denom = sqrtf(vr) / bc2 + 1e-8f;
                 const float upd = step_size * (mr / denom);
                 xs[a] = xs[a] - upd;
@@ -815,8 +850,10 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
 // in one batch of 16-byte stores, and read back in one batch - instead of leaving it to the register allocator, which
 // spills such values one by one and reloads them lazily, each with its own memory round trip, inside the latency-bound
 // phases (and whose choices move by +-15 % with semantically neutral edits).  The slot index goes through an opaque zero
-// (one per park / unpark site, with a memory clobber), so the compiler can neither promote the array to registers nor
-// forward a store to the matching load.
+// (one per park / unpark site, with a memory clobber), so the compiler can neither forward a store to the matching load
+// nor index the array statically; and the array is kept at 256 bytes: AMDGPU's alloca-to-vector promotion turned a
+// 128-byte one into a register vector with dynamic indexing (3,000 spilled registers, 4x the step time), and a volatile
+// one into uncached flat accesses.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int opaque_zero() {
     int z;
@@ -824,8 +861,7 @@ __device__ __forceinline__ int opaque_zero() {
     return z;
 }
 constexpr int PARK_KNN = 0;       // 4 slots per KnnPt: ka at 0, kb at 4
-constexpr int PARK_ADAM = 8;      // 3 slots: mm[6], vv[6]
-constexpr int PARK_SLOTS = 11;
+constexpr int PARK_SLOTS = 16;     // (8 used; see the note on alloca promotion above)
 
 __device__ __forceinline__ void park_knnpt(f32x4* park, int z, int base, const KnnPt& k) {
     park[z + base + 0] = f32x4{__int_as_float(k.cnt_f), __int_as_float(k.cnt_b), k.rho_f, k.rho_b};
@@ -841,13 +877,15 @@ __device__ __forceinline__ void unpark_knnpt(const f32x4* park, int z, int base,
     k.frag = (fl & 1) != 0;
     k.pend = (fl & 2) != 0;
 }
-__device__ __forceinline__ void park_adam(f32x4* park, int z, const AdamState& st) {
-    park[z + PARK_ADAM + 0] = f32x4{st.mm[0], st.mm[1], st.mm[2], st.mm[3]};
-    park[z + PARK_ADAM + 1] = f32x4{st.mm[4], st.mm[5], st.vv[0], st.vv[1]};
-    park[z + PARK_ADAM + 2] = f32x4{st.vv[2], st.vv[3], st.vv[4], st.vv[5]};
+// The Adam moments of the owner threads sleep in LDS between Adam phases: mv[3][OPT_THREADS] float4, slot k of thread
+// t at mv[k * OPT_THREADS + t] (conflict-free 16-byte accesses).
+__device__ __forceinline__ void store_adam(f32x4* mv, int t, const AdamState& st) {
+    mv[t] = f32x4{st.mm[0], st.mm[1], st.mm[2], st.mm[3]};
+    mv[OPT_THREADS + t] = f32x4{st.mm[4], st.mm[5], st.vv[0], st.vv[1]};
+    mv[2 * OPT_THREADS + t] = f32x4{st.vv[2], st.vv[3], st.vv[4], st.vv[5]};
 }
-__device__ __forceinline__ void unpark_adam(const f32x4* park, int z, AdamState& st) {
-    const f32x4 a = park[z + PARK_ADAM + 0], b = park[z + PARK_ADAM + 1], c = park[z + PARK_ADAM + 2];
+__device__ __forceinline__ void load_adam(const f32x4* mv, int t, AdamState& st) {
+    const f32x4 a = mv[t], b = mv[OPT_THREADS + t], c = mv[2 * OPT_THREADS + t];
     st.mm[0] = a.x; st.mm[1] = a.y; st.mm[2] = a.z; st.mm[3] = a.w; st.mm[4] = b.x; st.mm[5] = b.y;
     st.vv[0] = b.z; st.vv[1] = b.w; st.vv[2] = c.x; st.vv[3] = c.y; st.vv[4] = c.z; st.vv[5] = c.w;
 }

@@ -412,7 +412,7 @@ __device__ __forceinline__ void onet_prologue(const float* __restrict__ img, con
 
 constexpr size_t ONET_DEC_LDS = (size_t)OL_END * 4;
 constexpr int OL_G = OL_END;                                        // optimiser state behind the decoder's
-constexpr size_t ONET_OPT_LDS = ONET_DEC_LDS + MAXK * 16 * 2 + 16 + MAXK * 3 * 8 + 128 * 4;
+constexpr size_t ONET_OPT_LDS = ONET_DEC_LDS + MAXK * 16 * 2 + 16 + MAXK * 12 + 128 * 4;
 static_assert(ONET_OPT_LDS <= 160 * 1024, "LDS budget");
 
 __global__ __launch_bounds__(OPT_THREADS, 2) void onet_decode_kernel(const float* __restrict__ img, const float* __restrict__ small,
@@ -494,8 +494,9 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* G = reinterpret_cast<f32x4*>(smem + OL_G);                // occupancy gradient (+ BCE term in .w)
     f32x4* X = G + MAXK;                                             // current points; X[MAXK] = far-away dummy
-    long long* F = reinterpret_cast<long long*>(X + MAXK + 1);       // fixed-point neighbour-gradient scatter
-    float* scratch = reinterpret_cast<float*>(F + 3 * MAXK);         // 128 floats
+    const RepAcc F = {reinterpret_cast<long long*>(X + MAXK + 1),    // fixed-point repulsion-gradient scatter (knn_device.h)
+                      reinterpret_cast<int*>(reinterpret_cast<long long*>(X + MAXK + 1) + MAXK)};
+    float* scratch = reinterpret_cast<float*>(F.z + MAXK);           // 128 floats
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* pc = p + (size_t)cloud * K * 3;
     const int pa = tid, pb = tid + OPT_THREADS;
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
             }
         }
     }
-    for (int i = tid; i < MAXK * 3; i += OPT_THREADS) F[i] = 0;
+    for (int i = tid; i < MAXK; i += OPT_THREADS) { F.xy[i] = 0; F.z[i] = 0; }
     if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 0.f};
 
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};

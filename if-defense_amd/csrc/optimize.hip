@@ -27,6 +27,7 @@
 #include "knn_device.h"
 
 namespace ifd {
+constexpr int IFD_TRACE_BASE = 16;      // first trace slot in the device counter buffer (= IFD_N_COUNTERS)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -530,6 +531,12 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #define IFD_TV 1
 #endif
     constexpr int TV = IFD_TV;
+#ifdef IFD_SHIFT4
+    asm volatile("s_nop 0");
+#endif
+#ifdef IFD_ALIGN64
+    asm volatile(".p2align 6");
+#endif
     const int n = lane & 15, q = lane >> 4;
     LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
     asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
@@ -874,8 +881,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
     f32x4* X = G + MAXK;                                             // current points (x, y, z, 1); X[MAXK] = far-away dummy
     f32x4* PIX = X + MAXK + 1;                                       // their sampling coordinates (pix_encode)
-    long long* F = reinterpret_cast<long long*>(PIX + MAXK);         // fixed-point neighbour-gradient scatter
-    float* scratch = reinterpret_cast<float*>(F + 3 * MAXK);         // 128 floats
+    const RepAcc F = {reinterpret_cast<long long*>(PIX + MAXK),      // fixed-point repulsion-gradient scatter (knn_device.h)
+                      reinterpret_cast<int*>(reinterpret_cast<long long*>(PIX + MAXK) + MAXK)};
+    float* scratch = reinterpret_cast<float*>(F.z + MAXK);           // 128 floats
+    f32x4* MV = reinterpret_cast<f32x4*>(scratch + 128);             // [3][OPT_THREADS] Adam moments of the owner threads
 
     const int cloud = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -887,8 +896,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
-    // Per-thread state of the kNN / Adam phases (Adam moments, neighbour-list certificates): parked in scratch while the
-    // decoder tiles run (knn_device.h "Parking") - the tile phase owns the whole register file.
+    // Per-thread state of the kNN / Adam phases: the neighbour-list certificates are parked in scratch while the decoder
+    // tiles run (knn_device.h "Parking"), the Adam moments in LDS (MV) - the tile phase owns the whole register file.
     f32x4 park[PARK_SLOTS];
     {
         AdamState ast;
@@ -911,12 +920,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
         const KnnPt k0 = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false};   // ~10 front / ~35 total hits on a flat patch
         const int z = opaque_zero();
-        park_adam(park, z, ast);
+        if (owner) store_adam(MV, tid, ast);
         park_knnpt(park, z, PARK_KNN, k0);
         park_knnpt(park, z, PARK_KNN + 4, k0);
         park[z + PARK_KNN + 3] = f32x4{0.f, 0.f, 0.f, 0.f};          // rep_loss_a / rep_loss_b of the last step
     }
-    for (int i = tid; i < MAXK * 3; i += NW * 64) F[i] = 0;
+    for (int i = tid; i < MAXK; i += NW * 64) { F.xy[i] = 0; F.z[i] = 0; }
     if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 1.f};
 
     const DecConst dc = A.dc;
@@ -939,7 +948,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
     __syncthreads();
 #ifdef IFD_PROF
-    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(F + 3 * MAXK) + 64;   // [NW][PC_COUNT] behind `scratch`
+    unsigned long long* lprof = reinterpret_cast<unsigned long long*>(MV + 3 * OPT_THREADS);   // [NW][PC_COUNT] behind MV
     if (tid < NW * PC_COUNT) lprof[tid] = 0ull;
     __syncthreads();
 #endif
@@ -955,8 +964,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         const int lane = tid_s & 63, wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
         const bool owner = tid_s < OPT_THREADS;
         const int pa = owner ? tid_s : MAXK, pb = owner ? tid_s + OPT_THREADS : MAXK;
-#ifdef IFD_PROF
+#if defined(IFD_PROF)
         KnnCounters cn{lcnt, lane, lprof + wave * PC_COUNT};
+#elif defined(IFD_TRACE)
+        // time stamps of one step of cloud 0: [wave][32] behind the public counters; slot PC_KNN0 = step start, PC_BUILD /
+        // PC_EVAL / PC_REP = ends of those kNN sub-phases, PC_TILE0 + n = end of the wave's n-th tile, PC_TILES = tile loop
+        // left, PC_WAIT = barrier passed, PC_ADAM = Adam done
+        KnnCounters cn{lcnt, lane, (cloud == 0 && step == A.steps / 2 && counters != nullptr) ? counters + IFD_TRACE_BASE + wave * 32 : nullptr};
+        PROF_ACC(PC_KNN0);
+        int trace_tile = 0;
 #else
         KnnCounters cn{lcnt, lane};
 #endif
@@ -995,13 +1011,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
                 if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
             }
+#ifdef IFD_TRACE
+            PROF_ACC(PC_TILE0 + trace_tile);
+            ++trace_tile;
+#endif
         }
         PROF_ACC(pc_tiles);
         // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------
         AdamState ast;
         KnnPt ka, kb;
         const int z3 = opaque_zero();
-        unpark_adam(park, z3, ast);
+        load_adam(MV, min(tid_s, OPT_THREADS - 1), ast);
         unpark_knnpt(park, z3, PARK_KNN, ka);
         unpark_knnpt(park, z3, PARK_KNN + 4, kb);
         const f32x4 rl = park[z3 + PARK_KNN + 3];
@@ -1028,7 +1048,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             const int pt = q ? pb : pa;
             if (pt < K) { const f32x4 x = X[pt]; PIX[pt] = pix_encode(x.x, x.y, x.z, dc); }
         }
-        park_adam(park, opaque_zero(), ast);
+        if (owner) store_adam(MV, tid_s, ast);
         if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
         __syncthreads();
         PROF_ACC(pc_adam);
@@ -1052,7 +1072,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
     AdamState ast;
-    unpark_adam(park, opaque_zero(), ast);
+    load_adam(MV, min(tid, OPT_THREADS - 1), ast);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int pt = q ? pb : pa;
@@ -1170,9 +1190,9 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 // host launchers
 // ---------------------------------------------------------------------------------------------
 #ifdef IFD_PROF
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 3 * 8 + 128 * 4 + 8 * 8 * 8;
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 12 + 128 * 4 + 3 * OPT_THREADS * 16 + 8 * 8 * 8;
 #else
-constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 3 * 8 + 128 * 4;   // 142,112 B
+constexpr size_t OPT_LDS = DEC_FLOATS * 4 + MAXK * 16 * 3 + 16 + MAXK * 12 + 128 * 4 + 3 * OPT_THREADS * 16;   // 154,400 B
 #endif
 constexpr size_t DEC_LDS = DEC_FLOATS * 4;
 constexpr size_t REP_LDS = MAXK * 16 + MAXK * 3 * 8 + 64;

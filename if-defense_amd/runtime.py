@@ -244,6 +244,13 @@ class Restorer:
                 "mesh_points": int(buf[8]), "mesh_rounds": int(buf[9]),
                 "prof_cycles": [int(buf[i]) for i in range(8, 16)]}      # only in -DIFD_PROF diagnostic builds
 
+    def wave_trace(self):
+        """Time stamps (shader cycles) of one optimiser step of cloud 0, [8 waves][32 slots] - only filled by a
+        -DIFD_TRACE diagnostic build of libifd.so (scripts/trace_step.py)."""
+        buf = (C.c_uint64 * (16 + 8 * 32))()
+        self._check(self.lib.ifd_get_counters(self.ctx, buf, 16 + 8 * 32))
+        return [[int(buf[16 + w * 32 + i]) for i in range(32)] for w in range(8)]
+
     def normalize_batch_pc(self, points: torch.Tensor) -> torch.Tensor:
         """normalize_batch_pc (opt_defense.py:76-83); returns a new tensor."""
         p = _f32(points, self.device).clone()
