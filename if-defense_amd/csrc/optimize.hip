@@ -430,6 +430,23 @@ __device__ __forceinline__ void mfma16(const WFrag& f, const f32x8& in, Acc2& ac
 // interleave pattern of one region: 16 x { 1 MFMA, NV VALU, ND DS reads }, then close the region
 template <int NV, int ND>
 __device__ __forceinline__ void region_end() {
+#ifdef IFD_NO_INTERLEAVE
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+#endif
+#ifndef IFD_GROUP
+#define IFD_GROUP 4
+#endif
+    if (IFD_GROUP > 1) {
+#pragma unroll
+        for (int i = 0; i < 16 / IFD_GROUP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, IFD_GROUP, 0);
+            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, IFD_GROUP * NV, 0);
+            if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, IFD_GROUP * ND, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
