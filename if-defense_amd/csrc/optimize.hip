@@ -547,6 +547,15 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #ifndef IFD_TV
 #define IFD_TV 1
 #endif
+#ifndef IFD_PRIO_MLP
+#define IFD_PRIO_MLP 1
+#endif
+#ifndef IFD_PRIO_BWD
+#define IFD_PRIO_BWD 0
+#endif
+#ifndef IFD_PRIO_FWDS
+#define IFD_PRIO_FWDS 0
+#endif
     constexpr int TV = IFD_TV;
 #ifdef IFD_SHIFT4
     asm volatile("s_nop 0");
@@ -641,6 +650,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         load_taps(1, tap1, false);
         load_taps(2, tap2, false);               // all three planes in flight (192 registers; nothing else is live yet)
         __builtin_amdgcn_sched_barrier(0);
+        if (IFD_PRIO_FWDS) asm volatile("s_setprio %0" : : "n"(IFD_PRIO_FWDS));
         sample_fwd(0, tap0);
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(1, tap1);
@@ -649,6 +659,12 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // Wave priority: 1 while the wave streams MFMAs, 0 in its VALU / memory sections (and in the kNN / Adam phases).  An
+    // f32 MFMA and a vector instruction cannot overlap on a SIMD and every switch between the two costs issue cycles
+    // (scripts/mfma_valu_inwave.hip); with the MFMA wave preferred its stream runs back to back and the partner's vector
+    // work fills the gaps where it stalls, instead of the two alternating instruction by instruction (412 k -> 388 k
+    // cycles per step; the inverse assignment measured 425 k).
+    asm volatile("s_setprio %0" : : "n"(IFD_PRIO_MLP));
     // ---- fc_p on the matrix pipe: n_0 = [Wp | bp + bc_0] [x; 1]  (K = 4: one MFMA per M-tile and sub-tile) ----------
     // The lane's B operand is component q of its point (X.w = 1 carries the bias), its A operand row 16 mt + n, column q of
     // the [32][4] fc_p block.  (The biases of fc_c[i] are folded into the bias of the layer before: api.cpp build_dec_image.)
@@ -804,6 +820,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         mfma16(Ac, dn[1], dcc[1]);
         region_end<0, 1>();
     }
+    asm volatile("s_setprio %0" : : "n"(IFD_PRIO_BWD));
     float g[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
@@ -875,6 +892,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             v += __shfl_xor(v, 32);
             dx[t][a] = v;
         }
+    asm volatile("s_setprio 0");
 }
 
 __device__ __forceinline__ void load_dec_image(float* __restrict__ W, const float* __restrict__ img) {
