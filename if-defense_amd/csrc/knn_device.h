@@ -725,15 +725,8 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
             // A near-tie between the 5th and 6th key (equal above the index bits: ~10 % of the wave-steps have one
             // somewhere among their 128 points) is settled for THAT point by the exact wave-cooperative query below
             // (~2 k cycles) - re-running the whole wave on the exact insertion path cost ~70 k cycles each time.
-#ifdef IFD_NO_AMB_RESOLVE
-            const bool amb_any = (pa < K && !fail_a && keys6_ambiguous(qa)) || (pb < K && !fail_b && keys6_ambiguous(qb));
-            if (__any(amb_any)) exact = true;
-            const bool amb_a = false, amb_b = false;
-            if (!exact) {
-#else
             const bool amb_a = pa < K && !fail_a && keys6_ambiguous(qa), amb_b = pb < K && !fail_b && keys6_ambiguous(qb);
             {
-#endif
             keys6_to_top5(qa, ta);
             keys6_to_top5(qb, tb);
             if (__any(amb_a || amb_b)) cn.bump(CN_EXACT);

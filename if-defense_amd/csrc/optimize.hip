@@ -427,31 +427,17 @@ __device__ __forceinline__ void mfma16(const WFrag& f, const f32x8& in, Acc2& ac
             acc.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[2 * s + mt], in[s], acc.t[mt], 0, 0, 0);
 }
 
-// interleave pattern of one region: 16 x { 1 MFMA, NV VALU, ND DS reads }, then close the region
+// interleave pattern of one region: 4 x { 4 MFMAs, 4 NV VALU, 4 ND DS reads }, then close the region.  (An f32 MFMA and a
+// vector instruction exclude each other on the SIMD and every switch between the two kinds costs issue cycles, so they
+// alternate in groups, not one by one.)
 template <int NV, int ND>
 __device__ __forceinline__ void region_end() {
-#ifdef IFD_NO_INTERLEAVE
-    __builtin_amdgcn_sched_barrier(0);
-    return;
-#endif
-#ifndef IFD_GROUP
-#define IFD_GROUP 4
-#endif
-    if (IFD_GROUP > 1) {
+    constexpr int GROUP = 4;         // 2: 418 k, 4 / 8: 412 k, 16: 413 k cycles per step (one by one: 428 k)
 #pragma unroll
-        for (int i = 0; i < 16 / IFD_GROUP; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, IFD_GROUP, 0);
-            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, IFD_GROUP * NV, 0);
-            if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, IFD_GROUP * ND, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-        if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+    for (int i = 0; i < 16 / GROUP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GROUP, 0);
+        if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, GROUP * NV, 0);
+        if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, GROUP * ND, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -540,29 +526,10 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amdgpu_buffer_rsrc_t planes,
-                                              const float* __restrict__ planes_ptr, const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, const f32x4 xfa,
-                                              const f32x4 xfb, int lane,
+                                              const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, int lane,
                                               const DecConst dc, float thr, float inv_lb, bool want_loss,
                                               float (&bce)[2], float (&dx)[2][3]) {
-#ifndef IFD_TV
-#define IFD_TV 1
-#endif
-#ifndef IFD_PRIO_MLP
-#define IFD_PRIO_MLP 1
-#endif
-#ifndef IFD_PRIO_BWD
-#define IFD_PRIO_BWD 0
-#endif
-#ifndef IFD_PRIO_FWDS
-#define IFD_PRIO_FWDS 0
-#endif
-    constexpr int TV = IFD_TV;
-#ifdef IFD_SHIFT4
-    asm volatile("s_nop 0");
-#endif
-#ifdef IFD_ALIGN64
-    asm volatile(".p2align 6");
-#endif
+    constexpr int TV = 1;
     const int n = lane & 15, q = lane >> 4;
     LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
     asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
@@ -601,17 +568,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         for (int t = 0; t < 2; ++t) {
             int off = (geo[t].cell[a1] * RES + geo[t].cell[a0]) * (CH * 4) + (P * PLANE_FLOATS * 4 + q16);
             if (opaque) asm volatile("" : "+v"(off));      // backward re-gather: do not CSE with (and keep alive since) the forward one
-#ifdef IFD_GLOBAL_TAPS
-            const float* qp = planes_ptr + (off >> 2);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                tap[t][0][mt] = *reinterpret_cast<const f32x4*>(qp + 16 * mt);
-                tap[t][1][mt] = *reinterpret_cast<const f32x4*>(qp + CH + 16 * mt);
-                tap[t][2][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + 16 * mt);
-                tap[t][3][mt] = *reinterpret_cast<const f32x4*>(qp + RES * CH + CH + 16 * mt);
-            }
-            continue;
-#endif
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const u32x4v t0 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + 64 * mt, 0, 0);
@@ -650,7 +606,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         load_taps(1, tap1, false);
         load_taps(2, tap2, false);               // all three planes in flight (192 registers; nothing else is live yet)
         __builtin_amdgcn_sched_barrier(0);
-        if (IFD_PRIO_FWDS) asm volatile("s_setprio %0" : : "n"(IFD_PRIO_FWDS));
         sample_fwd(0, tap0);
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(1, tap1);
@@ -664,24 +619,11 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     // (scripts/mfma_valu_inwave.hip); with the MFMA wave preferred its stream runs back to back and the partner's vector
     // work fills the gaps where it stalls, instead of the two alternating instruction by instruction (412 k -> 388 k
     // cycles per step; the inverse assignment measured 425 k).
-    asm volatile("s_setprio %0" : : "n"(IFD_PRIO_MLP));
+    asm volatile("s_setprio 1");
     // ---- fc_p on the matrix pipe: n_0 = [Wp | bp + bc_0] [x; 1]  (K = 4: one MFMA per M-tile and sub-tile) ----------
     // The lane's B operand is component q of its point (X.w = 1 carries the bias), its A operand row 16 mt + n, column q of
     // the [32][4] fc_p block.  (The biases of fc_c[i] are folded into the bias of the layer before: api.cpp build_dec_image.)
     Acc2 net[2];
-#ifdef IFD_FCP_VALU
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WP + (16 * mt + j) * 4 + lo.q4 * 4);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const f32x4 xx = t ? xfb : xfa;
-                net[t].t[mt][j] = fmaf(wp.z, xx.z, fmaf(wp.y, xx.y, fmaf(wp.x, xx.x, wp.w)));
-            }
-        }
-#else
     {
         const float ap0 = W[DEC_OFF_WP + n * 4 + q], ap1 = W[DEC_OFF_WP + (16 + n) * 4 + q];
 #pragma unroll
@@ -691,7 +633,6 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             net[t].t[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, xq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
     }
-#endif
     WFrag A = load_wfrag<false>(Wd, lo);         // weights of the first layer (after the gather: its registers are free now)
     __builtin_amdgcn_sched_barrier(0);
 
@@ -820,7 +761,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         mfma16(Ac, dn[1], dcc[1]);
         region_end<0, 1>();
     }
-    asm volatile("s_setprio %0" : : "n"(IFD_PRIO_BWD));
+    asm volatile("s_setprio 0");
     float g[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
@@ -1014,8 +955,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         // ---- kNN + repulsion of the points this wave owns (all waves at the same time: a VALU-only wave next to an
         //      MFMA-heavy tile wave on a SIMD is starved, f32 MFMA and VALU issue do not overlap on gfx950) -------------
         if (wave < OWN_WAVES && use_rep) {
-            KnnPt ka, kb;
             float rep_loss_a, rep_loss_b;
+            KnnPt ka, kb;
             const int z = opaque_zero();
             unpark_knnpt(park, z, PARK_KNN, ka);
             unpark_knnpt(park, z, PARK_KNN + 4, kb);
@@ -1040,7 +981,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
             float bce[2], dx[2][3];
             const float* Xf = reinterpret_cast<const float*>(X) + (lane >> 4);      // component q of the point: fc_p's B operand
-            decoder_tile3<MODE_OPT>(W, plr, pl, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], X[tpa], X[tpb], lane, dc,
+            decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
                                     A.threshold, inv_lb, want_loss, bce, dx);
             if (lane < 16) {
                 if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
