@@ -31,11 +31,13 @@ FLOP_DENSE_PER_CLOUD = 2 * 15488 * 2 * K_POINTS * (ITERATIONS + 1)     # decoder
 F32_MFMA_PEAK_TFLOPS = 157.3                                          # MI355X_MICROARCH.md
 
 
-def synth_clouds(n, seed=1234):
-    """Area-uniform samples of 7 shape families, unit-sphere normalised like ModelNet40 inputs."""
-    rng = np.random.default_rng(seed)
+def synth_clouds(n, seed=1234, start=0):
+    """Area-uniform samples of 7 shape families, unit-sphere normalised like ModelNet40 inputs.
+    Cloud i (global index start + i) is drawn from its own generator keyed by (seed, index), so a rank can synthesise
+    just its shard and the array is the same whatever the world size."""
     air = np.load(os.path.join(ROOT, "tests", "golden", "convonet_golden.npz"))["raw"][0]
     out = np.empty((n, K_POINTS, 3), np.float32)
+    rng = None
 
     def unit(v):
         return v / np.linalg.norm(v, axis=1, keepdims=True)
@@ -49,7 +51,8 @@ def synth_clouds(n, seed=1234):
         return p
 
     for i in range(n):
-        kind = i % 7
+        rng = np.random.default_rng((seed, start + i))
+        kind = (start + i) % 7
         if kind == 0:
             p = unit(rng.standard_normal((K_POINTS, 3)))
         elif kind == 1:
@@ -114,6 +117,25 @@ def subsample_like(clouds, k=256, seed=1234):
     return np.stack([c[np.sort(rng.choice(len(c), k, replace=False))] for c in clouds]).astype(np.float32)
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_sha():
+    """Hash of the optimiser kernel's sources (the stamp scripts/summarise_profiles.py puts on roofline_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("optimize.hip", "knn_device.h", "ifd_device.h"):
+        h.update(open(os.path.join(ROOT, "if-defense_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(clouds, n_sample=16, budget_s=15.0, onet=False):
     """The CPU oracle (a port of the reference's op sequence: bmm-kNN + topk, autograd, torch.optim.Adam) timed
     on the host cores on a bounded sample, scaled to 501 steps.  Reported next to the GPU number, not a target.
@@ -148,8 +170,74 @@ def cpu_baseline(clouds, n_sample=16, budget_s=15.0, onet=False):
     t_opt = time.perf_counter() - t0
     per_cloud = (t_pre + t_opt / n_steps * (ITERATIONS + 1)) / n_sample
     return {"value": round(1.0 / per_cloud, 4), "unit": "clouds/s", "cores": threads, "kind": "port",
+            "host_cpu": host_cpu_model(), "host_cores": os.cpu_count(),
             "sample": "%d clouds: SOR+preprocess+encoder once (%.2f s) + %d of %d Adam steps (%.2f s), scaled to %d steps"
                       % (n_sample, t_pre, n_steps, ITERATIONS + 1, t_opt, ITERATIONS + 1)}
+
+
+def extras(dev):
+    """Bounded side measurements carried in the N = 1 line (a few seconds each; none of them is the headline):
+    the reference's op sequence run unfused by PyTorch-ROCm on the same GPU, and the two ONet rows of SURVEY 8f."""
+    import ifdefense_amd as I
+    out = {}
+    try:      # reference-style GPU baseline: the oracle's ops (bmm kNN + topk, autograd, torch.optim.Adam), one kernel per op
+        from oracle import convonet_oracle as O
+        n, steps = 64, 20
+        w = {k: v.to(dev) for k, v in O.to_torch(O.make_random_weights(0)).items()}
+        clouds = synth_clouds(n)
+        t0 = time.perf_counter()
+        keep, _ = O.sor_keep_mask(torch.from_numpy(clouds).to(dev))
+        keep = keep.cpu().numpy().astype(bool)
+        procs = [O.preprocess_pc(clouds[b][keep[b]]) for b in range(n)]
+        g = torch.Generator().manual_seed(0)
+        sel = torch.stack([torch.from_numpy(p[torch.randperm(len(p), generator=g)[:600].numpy()]) for p in procs]).to(dev)
+        init = torch.stack([torch.from_numpy(p[torch.randint(len(p), (K_POINTS,), generator=g).numpy()]) for p in procs])
+        init = (init + 0.01 * torch.randn(init.shape, generator=g)).clamp(-0.45, 0.45).to(dev)
+        with torch.no_grad():
+            planes = O.encode_inputs(w, sel)
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter() - t0
+        O.optimize_points(w, init[:2], {k: v[:2] for k, v in planes.items()}, iterations=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        O.optimize_points(w, init, planes, rep_weight=500.0, iterations=steps - 1)
+        torch.cuda.synchronize()
+        t_opt = time.perf_counter() - t0
+        out["reference_style_gpu"] = {"value": round(n / (t_pre + t_opt * (ITERATIONS + 1.0) / steps), 2), "unit": "clouds/s",
+                                      "what": "the reference's op sequence (oracle) run unfused by PyTorch-ROCm on this GPU: %d clouds, "
+                                              "%d of %d Adam steps timed, scaled" % (n, steps, ITERATIONS + 1)}
+    except Exception as e:      # noqa: BLE001  (a side measurement must never take the headline line down)
+        out["reference_style_gpu"] = {"error": str(e)[:200]}
+    try:      # ONet-Opt decoder variant (SURVEY N4): 256 clouds x 51 steps, scaled to 501
+        r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device=dev)
+        x = torch.from_numpy(synth_clouds(256)).to(dev)
+        prep = r.prepare(x, r.sor(x), n_sel=300, seed=1234)
+        c = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        r.optimize_points(prep["init"][:8], c[:8], rep_weight=500.0, steps=2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.optimize_points(prep["init"], c, rep_weight=500.0, steps=51)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        flop = 256 * K_POINTS * 51 * 2 * 2 * (10 * 256 * 256 + 4 * 256)
+        out["onet_opt"] = {"value": round(256 / (dt * (ITERATIONS + 1) / 51), 2), "unit": "clouds/s",
+                           "roofline_frac": round(flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                           "what": "ifd_onet_optimize, 256 clouds x 51 of 501 Adam steps, scaled (optimiser only)"}
+        # ONet-Mesh (SURVEY N3): MISE grid + marching cubes + surface samples, threshold at the field's median
+        gq = torch.Generator().manual_seed(9)
+        med = float(r.decode((torch.rand(8, 4096, 3, generator=gq) - 0.5) * 1.1, c[:8]).median())
+        thr = 1.0 / (1.0 + np.exp(-med))
+        r.mesh_sample(c[:4], threshold=thr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.mesh_sample(c[:64], threshold=thr)
+        torch.cuda.synchronize()
+        out["onet_mesh"] = {"value": round(64 / (time.perf_counter() - t0), 1), "unit": "clouds/s",
+                            "what": "ifd_onet_mesh_sample, 64 clouds, 32 -> 128 MISE grid, iso-surface at the field's median"}
+        r.close()
+    except Exception as e:      # noqa: BLE001
+        out["onet"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():
@@ -159,6 +247,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clouds", type=int, default=N_CLOUDS, help="clouds per GPU per step (default: MN40 test size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements (reference-style unfused "
+                    "GPU baseline, ONet-Opt, ONet-Mesh) that ride along in the N = 1 line")
     ap.add_argument("--workload", choices=("convonet-opt", "onet-opt"), default="convonet-opt",
                     help="convonet-opt = the BASELINE metric (default); onet-opt = the ONet-Opt decoder variant "
                          "(BASELINE config #1 model, SURVEY N4) at 500 iterations - an extra line, not the headline")
@@ -178,9 +268,9 @@ def main():
     torch.cuda.set_device(dev)
 
     total = a.clouds * world
-    all_clouds = synth_clouds(total)
     lo, hi, per = D.shard_range(total, rank, world)
-    x = torch.from_numpy(all_clouds[lo:hi]).to(dev)                     # resident in HBM before timing
+    my_clouds = synth_clouds(hi - lo, start=lo)                         # every rank synthesises only its own shard
+    x = torch.from_numpy(my_clouds).to(dev)                             # resident in HBM before timing
     if onet:
         r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device=dev)
         args = I.DefenseArgs(iterations=ITERATIONS, seed=1234, input_npoint=300)
@@ -204,9 +294,16 @@ def main():
 
     r.optimize_points = timed_optimize
 
+    gev = []
+
     def step():
         local_out = I.defend_point_cloud(r, x, args, cloud_index_base=lo, total_clouds=total, return_device=True)
-        return D.gather_shards(local_out, total, per)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        full = D.gather_shards(local_out, total, per)                   # the one collective of the path (RCCL all-gather)
+        g1.record()
+        gev.append((g0, g1))
+        return full
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,6 +314,7 @@ def main():
     for _ in range(a.warmup):
         out = step()
     ev.clear()
+    gev.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -235,10 +333,17 @@ def main():
         avg_ms = sum(kern_ms) / len(kern_ms)
         avg_clouds = sum(kern_clouds) / len(kern_clouds)
         achieved = flop_per_cloud * avg_clouds / (avg_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh; counters cannot be read inside this run):
+        # quoted only if they were measured on THIS kernel (source hash) and this launch size, else null
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tf) and not onet:
-            traffic = json.load(open(tf)).get("optimize_kernel_hbm_bytes_per_launch")
+        if os.path.exists(tf) and not onet and avg_clouds == N_CLOUDS:
+            tj = json.load(open(tf))
+            if tj.get("kernel_source_sha") == kernel_source_sha():
+                traffic = tj.get("optimize_kernel_hbm_bytes_per_launch")
+                traffic_src = "profiles/roofline_traffic.json (rocprofv3 PMC passes of this kernel, fetch factor %.2f)" % tj.get("fetch_factor", 2.0)
+            else:
+                traffic_src = "profiles/roofline_traffic.json is from another build of the kernel - not quoted"
         res = {
             "metric": "restored clouds/sec (1024-pt ModelNet40, %s 500 iters)" % ("ONet-Opt" if onet else "ConvONet-Opt"),
             "value": round(total * a.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": a.steps,
@@ -252,12 +357,15 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "ifd::onet_optimize_kernel" if onet else "ifd::optimize_kernel",
                          "achieved": round(achieved, 2),
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": traffic, "launch_ms": round(avg_ms, 2), "clouds_per_launch": avg_clouds,
-                         "flop_per_cloud": flop_per_cloud},
+                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(avg_ms, 2),
+                         "clouds_per_launch": avg_clouds, "flop_per_cloud": flop_per_cloud},
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
+            "gather_ms": round(sum(g0.elapsed_time(g1) for g0, g1 in gev) / max(1, len(gev)), 3),
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(all_clouds, onet=onet)
+            res["cpu_baseline"] = cpu_baseline(my_clouds, onet=onet)
+        if world == 1 and not onet and not a.no_extras:
+            res["extras"] = extras(dev)
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

@@ -32,7 +32,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL (before the first HIP call of the process)
+    # RCCL shares buffers between the ranks' processes through HIP IPC handles; the hosts of this build only support the
+    # dmabuf flavour (HSA_ENABLE_IPC_MODE_LEGACY=0; with the legacy mode hipIpcGetMemHandle fails with "invalid argument").
+    # It must be in the environment before the first HIP call of the process.  Only a default: export the variable
+    # yourself (any value) to override it on hosts that need the legacy mode.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -42,6 +46,22 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             kw["device_id"] = torch.device("cuda", local)      # bind the RCCL communicator (and barrier()) to this rank's GPU
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def any_rank_failed(failed: bool, device=None) -> bool:
+    """One MAX all-reduce of a status flag: True on every rank if any rank reports a failure (single process: `failed`)."""
+    if not dist.is_initialized():
+        return bool(failed)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    flag = torch.tensor([1.0 if failed else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(flag.item() > 0)
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def gather_shards(local: torch.Tensor, n_total: int, per: int) -> torch.Tensor:

@@ -80,7 +80,11 @@ def load_config(path, default_path=None, model="convonet"):
     raises on PyYAML >= 6)."""
     DEFAULT_CFG = DEFAULT_CFG_ONET if model == "onet" else globals()["DEFAULT_CFG"]
     if not os.path.exists(path):
-        return DEFAULT_CFG
+        # the shipped yaml files are not part of this package: the parser's DEFAULT path falls back to the resolved
+        # shipped configuration; any other path that does not exist is an error, like in the reference (open() raises)
+        if path in ('configs/onet_mn40.yaml', 'configs/convonet_3plane_mn40.yaml', 'configs/default.yaml'):
+            return DEFAULT_CFG
+        raise SystemExit("config file not found: %s" % path)
     with open(path) as f:
         special = yaml.safe_load(f) or {}
     inherit = special.get('inherit_from')
@@ -119,23 +123,68 @@ def check_supported(cfg, model="convonet"):
                          "(configs/convonet_3plane_mn40.yaml) is built for MI355X")
 
 
-def main(argv=None, model="convonet"):
-    """model = "convonet": ConvONet/opt_defense.py; "onet": ONet/opt_defense.py (python -m ifdefense_amd.onet_opt_defense)."""
+# Sizes the kernels hold in LDS (include/ifd.h): more than the reference's Python needs, but finite.
+MAX_SAMPLE_NPOINT = 1024      # optimised points per cloud (MAXK)
+MAX_INPUT_POINTS = 2048       # points per input cloud (SOR / preprocess)
+MAX_ENCODER_POINTS = 1024     # data.pointcloud_n, the encoder subset
+
+
+def list_inputs(data_root, train):
+    if not train and os.path.isdir(data_root):
+        return [os.path.join(data_root, f) for f in sorted(os.listdir(data_root))      # (the reference: os.listdir order)
+                if os.path.isfile(os.path.join(data_root, f))]
+    return [data_root]
+
+
+def validate_limits(args, cfg, files):
+    """Reject what the kernels cannot hold BEFORE the checkpoint is loaded and the process group exists - on every rank,
+    with the limit named (the reference accepts any size; here a too-large one would only surface as IFD_ERR_ARG after
+    minutes of set-up)."""
+    if not 6 <= args.sample_npoint <= MAX_SAMPLE_NPOINT:
+        raise SystemExit("--sample_npoint %d: this build optimises 6 ... %d points per cloud" % (args.sample_npoint, MAX_SAMPLE_NPOINT))
+    n_in = int(cfg['data']['pointcloud_n'])
+    if not 1 <= n_in <= MAX_ENCODER_POINTS:
+        raise SystemExit("data.pointcloud_n %d: the encoder takes at most %d points per cloud" % (n_in, MAX_ENCODER_POINTS))
+    if args.batch_size < 1 or args.iterations < 0:
+        raise SystemExit("--batch_size must be >= 1 and --iterations >= 0")
+    for path in files:
+        if not os.path.isfile(path):
+            raise SystemExit("input file not found: %s" % path)
+        npz = np.load(path)
+        for key in (('train_pc', 'train_label', 'test_pc', 'test_label') if args.train else ('test_pc', 'test_label')):
+            if key not in npz.files:
+                raise SystemExit("%s: missing array %r" % (path, key))
+        for key in (('train_pc', 'test_pc') if args.train else ('test_pc',)):
+            shp = npz[key].shape
+            if len(shp) != 3 or shp[2] < 3:
+                raise SystemExit("%s: %s must be [N, K, >= 3], got %s" % (path, key, (shp,)))
+            if shp[1] > MAX_INPUT_POINTS or shp[1] < 6:
+                raise SystemExit("%s: %s has %d points per cloud; this build takes 6 ... %d" % (path, key, shp[1], MAX_INPUT_POINTS))
+
+
+def main(argv=None, model="convonet", restorer_factory=None, backend=None, device=None):
+    """model = "convonet": ConvONet/opt_defense.py; "onet": ONet/opt_defense.py (python -m ifdefense_amd.onet_opt_defense).
+    restorer_factory / backend / device: test hooks (a stand-in model on CPU under gloo); the CLI leaves them alone."""
     args = build_parser(model).parse_args(argv)
     cfg = load_config(args.config, 'configs/default.yaml', model)
     check_supported(cfg, model)
+    files = list_inputs(args.data_root, args.train)
+    validate_limits(args, cfg, files)
 
     import torch
-    from . import (DefenseArgs, OnetRestorer, Restorer, defend_npz_test_data, defend_npz_train_test_data,
-                   defend_point_cloud, weights)
+    from . import DefenseArgs, defend_npz_test_data, defend_npz_train_test_data, defend_point_cloud
     from . import dist as D
 
-    rank, world, local = D.init_from_env()
-    device = torch.device('cuda', local)
+    rank, world, local = D.init_from_env(backend)
+    device = torch.device('cuda', local) if device is None else torch.device(device)
     wpath = args.weights or cfg['test']['model_file']
-    if model == "onet":
+    if restorer_factory is not None:
+        r = restorer_factory(cfg, device)
+    elif model == "onet":
+        from . import OnetRestorer, weights
         r = OnetRestorer(weights.load_checkpoint(wpath, "onet"), device=device, threshold=cfg['test']['threshold'])
     else:
+        from . import Restorer, weights
         r = Restorer(weights.load_checkpoint(wpath), device=device, padding=cfg['data'].get('padding', 0.1),
                      threshold=cfg['test']['threshold'])
     dargs = DefenseArgs(sample_npoint=args.sample_npoint, padding_scale=args.padding_scale, init_sigma=args.init_sigma,
@@ -149,22 +198,29 @@ def main(argv=None, model="convonet"):
         return out.cpu().numpy()
 
     def one_file(path):
+        """Every rank restores its shards (the all-gathers inside `defend` are collective), rank 0 writes the file.  A
+        failure on one rank (unwritable output, a bad array) must not leave the others waiting in the next file's
+        all-gather: the ranks agree on a status after every file and stop together."""
         fn = defend_npz_train_test_data if args.train else defend_npz_test_data
-        if rank == 0:
-            fn(r, path, dargs, defend=defend)
-        else:                                   # non-zero ranks compute their shards, rank 0 writes the file
-            npz = np.load(path)
-            for key in (('train_pc', 'test_pc') if args.train else ('test_pc',)):
-                defend(npz[key][..., :3])
+        err = None
+        try:
+            if rank == 0:
+                fn(r, path, dargs, defend=defend)
+            else:                               # non-zero ranks compute their shards, rank 0 writes the file
+                npz = np.load(path)
+                for key in (('train_pc', 'test_pc') if args.train else ('test_pc',)):
+                    defend(npz[key][..., :3])
+        except Exception as e:                  # noqa: BLE001  (reported below, on every rank)
+            err = e
+        bad = D.any_rank_failed(err is not None, device)
+        if err is not None:
+            raise SystemExit("rank %d failed on %s: %s: %s" % (rank, path, type(err).__name__, err))
+        if bad:
+            raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
 
-    data_root = args.data_root
-    if not args.train and os.path.isdir(data_root):
-        for file in sorted(os.listdir(data_root)):       # (the reference iterates os.listdir order)
-            one = os.path.join(data_root, file)
-            if os.path.isfile(one):
-                one_file(one)
-    else:
-        one_file(data_root)
+    for one in files:
+        one_file(one)
+    D.shutdown()
     return 0
 
 

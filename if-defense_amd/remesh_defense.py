@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-from .opt_defense import check_supported, load_config, str2bool
+from .opt_defense import check_supported, list_inputs, load_config, str2bool, validate_limits
 
 
 def build_parser():
@@ -45,6 +45,10 @@ def main(argv=None):
         raise SystemExit("unsupported generation config: only resolution_0 32 / upsampling_steps 2 without refinement or "
                          "simplification (configs/default.yaml:64-74) is built for MI355X")
 
+    files = list_inputs(args.data_root, args.train)
+    args.batch_size, args.iterations = 1, 0                       # (not flags of this CLI; validate_limits looks at them)
+    validate_limits(args, cfg, files)
+
     import torch
     from . import DefenseArgs, OnetRestorer, defend_npz_test_data, remesh_point_cloud, weights, get_save_name
     from . import dist as D
@@ -61,7 +65,7 @@ def main(argv=None):
                                                                             normalize=normalize), pc)
         return out.cpu().numpy()
 
-    def one_file(path):
+    def one_file_work(path):
         if args.train:                                            # remesh_defense.py:187-223 (train split not normalised)
             npz = np.load(path)
             tr = defend(npz['train_pc'][..., :3], normalize=False)
@@ -76,14 +80,18 @@ def main(argv=None):
         else:
             defend(np.load(path)['test_pc'][..., :3])
 
-    data_root = args.data_root
-    if not args.train and os.path.isdir(data_root):
-        for file in sorted(os.listdir(data_root)):
-            one = os.path.join(data_root, file)
-            if os.path.isfile(one):
-                one_file(one)
-    else:
-        one_file(data_root)
+    for path in files:
+        err = None
+        try:
+            one_file_work(path)
+        except Exception as e:                  # noqa: BLE001  (the ranks agree on a status and stop together)
+            err = e
+        bad = D.any_rank_failed(err is not None, torch.device('cuda', local))
+        if err is not None:
+            raise SystemExit("rank %d failed on %s: %s: %s" % (rank, path, type(err).__name__, err))
+        if bad:
+            raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
+    D.shutdown()
     return 0
 
 

@@ -15,5 +15,10 @@ for set in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum";
     timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o $name -- \
         python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/$name.err
 done
+# calibration of FETCH_SIZE on the decoder tile's gather pattern (a known byte count, every 128-byte line once)
+if [ -x $R/scripts/gather_calib ]; then
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib -o calib -- \
+        $R/scripts/gather_calib > $OUT/calib.json 2> $OUT/calib.err
+fi
 cd $R
 python scripts/summarise_profiles.py $OUT $TAG

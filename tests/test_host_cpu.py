@@ -25,14 +25,16 @@ def test_cli_flags_and_defaults_match_reference():
 
 def test_config_loading(tmp_path):
     from ifdefense_amd import opt_defense as od
-    cfg = od.load_config(str(tmp_path / "missing.yaml"))
+    cfg = od.load_config('configs/convonet_3plane_mn40.yaml')          # the parser's default: shipped values, no file needed
     assert cfg['test']['threshold'] == 0.2 and cfg['data']['pointcloud_n'] == 600
     od.check_supported(cfg)
+    with pytest.raises(SystemExit):                                     # a mistyped explicit path is an error, like the reference's open()
+        od.load_config(str(tmp_path / "missing.yaml"))
     (tmp_path / "default.yaml").write_text("data:\n  padding: 0.1\n  pointcloud_n: 256\ntest:\n  threshold: 0.5\n")
     (tmp_path / "c.yaml").write_text("data:\n  pointcloud_n: 600\ntest:\n  threshold: 0.2\n  model_file: w.pth\n")
     cfg = od.load_config(str(tmp_path / "c.yaml"), str(tmp_path / "default.yaml"))
     assert cfg['data'] == {'pointcloud_n': 600, 'padding': 0.1, 'dim': 3} and cfg['test']['model_file'] == 'w.pth'
-    bad = od.load_config(str(tmp_path / "missing.yaml"))
+    bad = od.load_config('configs/convonet_3plane_mn40.yaml')
     bad = {**bad, 'model': {**bad['model'], 'c_dim': 128}}
     with pytest.raises(SystemExit):
         od.check_supported(bad)
@@ -44,7 +46,7 @@ def test_onet_cli_config_and_save_name(tmp_path):
     from ifdefense_amd import opt_defense as od
     a = od.build_parser("onet").parse_args([])
     assert a.config == 'configs/onet_mn40.yaml' and a.iterations == 200 and a.batch_size == 192      # ONet/opt_defense.py:24-53
-    cfg = od.load_config(str(tmp_path / "missing.yaml"), None, "onet")
+    cfg = od.load_config('configs/onet_mn40.yaml', None, "onet")
     assert cfg['data']['pointcloud_n'] == 300 and cfg['test']['threshold'] == 0.2 and cfg['model']['z_dim'] == 0
     od.check_supported(cfg, "onet")
     with pytest.raises(SystemExit):
@@ -154,3 +156,138 @@ def test_world2_gloo_shard_and_allgather(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     # one marker file per rank (the two ranks' stdout lines interleave character by character)
     assert (tmp_path / "ok_rank0_of_2").exists() and (tmp_path / "ok_rank1_of_2").exists(), r.stdout + r.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# The N > 1 path through the REAL CLI (opt_defense.main) on CPU: gloo ranks, a stand-in model whose "restoration" is a
+# deterministic function of (cloud, global index, seed, loss_batch), an uneven split, fewer clouds than ranks, the
+# --train two-array path, the rank-0-only write, and a failing write that must stop every rank instead of hanging them.
+# ------------------------------------------------------------------------------------------------
+_CLI_SCRIPT = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+from ifdefense_amd import opt_defense
+
+
+class FakeRestorer:
+    """The call seams of Restorer on the CPU: every output row depends on its cloud, its GLOBAL index and its 1/B group, so
+    a wrong shard range, index base or gather order changes the file."""
+    model_name = "convonet"
+
+    def __init__(self, cfg, device):
+        self.device = torch.device(device)
+
+    def sor(self, x, k, alpha):
+        return None
+
+    def prepare(self, xb, keep, n_sel, n_opt, padding_scale, init_sigma, seed, cloud_index_base):
+        idx = torch.arange(cloud_index_base, cloud_index_base + xb.shape[0], dtype=torch.float32)
+        init = xb[:, :1, :].mean(dim=1, keepdim=True).repeat(1, n_opt, 1) + idx[:, None, None] + 0.001 * seed
+        return {"sel": xb[:, :n_sel], "t_per_cloud": None, "init": init}
+
+    def encode_inputs(self, sel, t):
+        return sel.sum(dim=(1, 2))
+
+    def optimize_points(self, init, planes, rep_weight, iterations, lr, loss_batch, normalize):
+        return init + planes[:, None, None] * 1e-3 + loss_batch.float()[:, None, None] * 1e-2 + iterations
+
+
+argv = sys.argv[1:]
+rc = opt_defense.main(argv, restorer_factory=FakeRestorer, backend="gloo", device="cpu")
+open(os.path.join(%(out)r, "done_rank%%s" %% os.environ.get("RANK", "0")), "w").write(str(rc))
+'''
+
+
+def _run_cli(tmp_path, world, argv, expect_ok=True):
+    import socket
+    script = tmp_path / "cli_run.py"
+    script.write_text(_CLI_SCRIPT % {"root": ROOT, "out": str(tmp_path)})
+    for f in tmp_path.glob("done_rank*"):
+        f.unlink()
+    if world == 1:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, str(script)] + argv, capture_output=True, text=True, env=env, timeout=300)
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                            "--master-addr", "127.0.0.1", "--master-port", port, str(script)] + argv,
+                           capture_output=True, text=True, env=env, timeout=300)
+    if expect_ok:
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert len(list(tmp_path.glob("done_rank*"))) == world, r.stdout + r.stderr
+    return r
+
+
+def test_cli_sharded_write_uneven_split_empty_shards_and_train_path(tmp_path):
+    rng = np.random.default_rng(3)
+    pc7 = rng.normal(size=(7, 40, 6)).astype(np.float32)            # 7 clouds (uneven over 2 and 3 ranks), normals to slice off
+    pc2 = rng.normal(size=(2, 40, 3)).astype(np.float32)            # fewer clouds than ranks at world 3: an empty shard
+    src = tmp_path / "adv.npz"
+    np.savez(src, test_pc=pc7, test_label=np.arange(7), target_label=np.arange(7)[::-1].copy())
+    small = tmp_path / "two.npz"
+    np.savez(small, test_pc=pc2, test_label=np.array([3, 4]))
+    both = tmp_path / "tt.npz"
+    np.savez(both, train_pc=pc7[:5], train_label=np.arange(5), test_pc=pc2, test_label=np.array([3, 4]))
+    flags = ["--iterations=3", "--batch_size=4", "--seed=9", "--sample_npoint=16"]
+    outs = {}
+    for world in (1, 2, 3):
+        _run_cli(tmp_path, world, ["--data_root", str(src)] + flags)
+        _run_cli(tmp_path, world, ["--data_root", str(small)] + flags)
+        _run_cli(tmp_path, world, ["--data_root", str(both), "--train=True"] + flags)
+        outs[world] = {n: dict(np.load(tmp_path / "ConvONet-Opt" / ("convonet_opt-" + n))) for n in ("adv.npz", "two.npz", "tt.npz")}
+        for n in ("adv.npz", "two.npz", "tt.npz"):
+            os.remove(tmp_path / "ConvONet-Opt" / ("convonet_opt-" + n))
+    one = outs[1]
+    assert sorted(one["adv.npz"]) == ["target_label", "test_label", "test_pc"]
+    assert one["adv.npz"]["test_pc"].shape == (7, 16, 3) and one["adv.npz"]["test_pc"].dtype == np.float32
+    assert one["adv.npz"]["test_label"].dtype == np.uint8 and one["adv.npz"]["target_label"].tolist() == list(range(7))[::-1]
+    # the stand-in encodes the global index and the reference batch (4, the last one 3) of every cloud
+    lb = np.array([4, 4, 4, 4, 3, 3, 3], np.float32)
+    base = pc7[:, :1, :3].mean(axis=1) + np.arange(7, dtype=np.float32)[:, None] + 0.009
+    want = base + pc7[:, :, :3].sum(axis=(1, 2))[:, None] * 1e-3 + lb[:, None] * 1e-2 + 3      # (the 600-point subset takes all 40)
+    np.testing.assert_allclose(one["adv.npz"]["test_pc"][:, 0], want, rtol=1e-5, atol=1e-5)
+    assert sorted(one["tt.npz"]) == ["test_label", "test_pc", "train_label", "train_pc"]
+    assert one["tt.npz"]["train_pc"].shape == (5, 16, 3) and one["tt.npz"]["test_pc"].shape == (2, 16, 3)
+    for world in (2, 3):                                            # P4 through the CLI: any world size writes the same file
+        for n in one:
+            for k in one[n]:
+                assert np.array_equal(outs[world][n][k], one[n][k]), (world, n, k)
+
+
+def test_cli_rejects_sizes_and_missing_files_before_loading_anything(tmp_path):
+    from ifdefense_amd import opt_defense
+    ok = tmp_path / "ok.npz"
+    np.savez(ok, test_pc=np.zeros((2, 64, 3), np.float32), test_label=np.zeros(2))
+    big = tmp_path / "big.npz"
+    np.savez(big, test_pc=np.zeros((1, 4096, 3), np.float32), test_label=np.zeros(1))
+    nolabel = tmp_path / "nolabel.npz"
+    np.savez(nolabel, test_pc=np.zeros((1, 64, 3), np.float32))
+
+    def boom(cfg, device):                                          # validation must come first: the model is never built
+        raise AssertionError("the model was built before the arguments were validated")
+
+    for argv, word in ((["--data_root", str(ok), "--sample_npoint", "2048"], "sample_npoint"),
+                       (["--data_root", str(big)], "points per cloud"),
+                       (["--data_root", str(nolabel)], "test_label"),
+                       (["--data_root", str(tmp_path / "missing.npz")], "not found"),
+                       (["--data_root", str(ok), "--config", str(tmp_path / "typo.yaml")], "config file not found")):
+        with pytest.raises(SystemExit) as e:
+            opt_defense.main(argv, restorer_factory=boom, backend="gloo", device="cpu")
+        assert word in str(e.value), (argv, str(e.value))
+
+
+def test_cli_failing_write_stops_every_rank(tmp_path):
+    """Rank 0 cannot write its output (the directory name is taken by a file): the other rank must leave with an error
+    too - within seconds, not by a collective timeout - and no rank reports success."""
+    src = tmp_path / "adv.npz"
+    np.savez(src, test_pc=np.zeros((5, 40, 3), np.float32), test_label=np.arange(5))
+    (tmp_path / "ConvONet-Opt").write_text("in the way")
+    r = _run_cli(tmp_path, 2, ["--data_root", str(src), "--iterations=1", "--sample_npoint=16"], expect_ok=False)
+    assert r.returncode != 0
+    assert not list(tmp_path.glob("done_rank*")), r.stdout + r.stderr
+    assert "failed on" in (r.stdout + r.stderr) and "another rank failed" in (r.stdout + r.stderr), r.stdout + r.stderr
