@@ -1,5 +1,9 @@
-// C ABI of libifd.so (see include/ifd.h).  Host-side only: context, weight re-packing, argument
-// validation and kernel launches.  Never throws, never exits, never synchronises the device.
+// C ABI of libifd.so (see include/ifd.h).  Host-side only: context, weight re-packing, argument validation and kernel
+// launches.  Never throws, never exits.  Every call runs on the context's own device (DeviceGuard).  Calls only enqueue
+// work on the caller's stream, with these exceptions, which block the host: ifd_create / ifd_onet_create / ifd_destroy
+// (allocation, upload), ifd_get_counters (device-to-host copy), ifd_onet_mesh_sample (one stream synchronisation per MISE
+// round: the host reads how many grid points to evaluate), and any call that needs MORE context workspace than every
+// earlier call on that context (the old buffer is freed after a device synchronisation; steady-state calls never do).
 #include "../../include/ifd.h"
 
 #include <hip/hip_runtime.h>
@@ -110,6 +114,16 @@ struct ifd_ctx {
 
 namespace {
 
+// A context is bound to one device (include/ifd.h).  Every entry point that takes a context makes that device current for
+// the duration of the call - launches, workspace allocations and the rare synchronisations all go to ctx->device whatever
+// the caller's current device is - and restores the caller's device on the way out.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(const ifd_ctx* ctx);
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int fail(ifd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
     if (ctx) {
         ctx->err = what;
@@ -117,6 +131,18 @@ int fail(ifd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
     }
     return code;
 }
+
+DeviceGuard::DeviceGuard(const ifd_ctx* ctx) {
+    int cur = -1;
+    if (!ctx || hipGetDevice(&cur) != hipSuccess) { ok = ctx != nullptr; return; }
+    if (cur != ctx->device) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { ok = false; return; }
+        prev = cur;
+    }
+}
+#define IFD_ON_CTX_DEVICE(ctx)                                  \
+    DeviceGuard ifd_device_guard_(ctx);                          \
+    if (!ifd_device_guard_.ok) return fail(ctx, IFD_ERR_HIP, "cannot make the context's device current")
 
 // Build the LDS image of the decoder parameters.
 std::vector<float> build_dec_image(const float* w) {
@@ -364,6 +390,7 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
 
 void ifd_destroy(ifd_ctx* ctx) {
     if (!ctx) return;
+    DeviceGuard guard(ctx);
     if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
@@ -380,6 +407,7 @@ void ifd_destroy(ifd_ctx* ctx) {
 int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uint8_t* keep_mask, double* value,
             void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (!pc || !keep_mask || B < 1 || K < 2 || K > 2048 || k < 1 || k > 7 || k >= K)
         return fail(ctx, IFD_ERR_ARG, "ifd_sor: bad argument (2 <= K <= 2048, 1 <= k <= 7)");
     hipError_t e = launch_sor(pc, B, K, k, (double)alpha, keep_mask, value, static_cast<hipStream_t>(stream));
@@ -390,6 +418,7 @@ int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, 
                 const int32_t* sel_idx, const int32_t* init_idx, const float* noise, float* sel, int32_t* t_per_cloud,
                 float* init_points, int32_t* n_kept, float* proc, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (!pc || !prm || prm->struct_size != (int32_t)sizeof(ifd_prep_params) || !sel || !t_per_cloud || !init_points ||
         B < 1 || K < 1 || K > 2048 || prm->n_sel < 1 || prm->n_sel > 1024 || prm->n_opt < 1)
         return fail(ctx, IFD_ERR_ARG, "ifd_prepare: bad argument (K <= 2048, n_sel <= 1024)");
@@ -405,6 +434,7 @@ int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, 
 int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* planes_pre,
                       float* c_points, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_encode_points: not a ConvONet context");
     if (!sel || !planes_pre || B < 1 || Tmax < 1 || Tmax > 1024)
         return fail(ctx, IFD_ERR_ARG, "ifd_encode_points: bad argument (1 <= Tmax <= 1024)");
@@ -417,6 +447,7 @@ int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
 
 int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_unet: not a ConvONet context");
     if (!planes_pre || !planes || B < 1) return fail(ctx, IFD_ERR_ARG, "ifd_unet: bad argument");
     hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, unet_workspace_floats(3 * B) * sizeof(float));
@@ -428,6 +459,7 @@ int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* 
 int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* planes,
                       void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_encode_planes: not a ConvONet context");
     if (!sel || !planes || B < 1 || Tmax < 1 || Tmax > 1024)
         return fail(ctx, IFD_ERR_ARG, "ifd_encode_planes: bad argument (1 <= Tmax <= 1024)");
@@ -446,6 +478,7 @@ int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
 int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,
                void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_decode: not a ConvONet context (use ifd_onet_decode)");
     if (!planes || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_decode: bad argument");
     hipError_t e = launch_decode(ctx->d_dec_img, planes, p, B, K, logits, dlogit_dp, ctx->dc,
@@ -456,6 +489,7 @@ int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, 
 int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx,
                   void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (!p || !loss || bad_bk(B, K)) return fail(ctx, IFD_ERR_ARG, "ifd_repulsion: bad argument (6 <= K <= 1024)");
     hipError_t e = launch_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f,
                                     static_cast<hipStream_t>(stream));
@@ -465,6 +499,7 @@ int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, const ifd_opt_params* prm,
                  const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: not a ConvONet context (use ifd_onet_optimize)");
     if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 1024)");
@@ -490,6 +525,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
 
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
     if (!ctx || !out_host || n < 1) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     unsigned long long tmp[N_COUNTERS_DEV] = {0};
     hipError_t e = hipMemcpy(tmp, ctx->d_counters, sizeof(tmp), hipMemcpyDeviceToHost);   // synchronises
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_get_counters", e);
@@ -503,6 +539,7 @@ int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
 
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (!p || B < 1 || K < 1 || K > MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument");
     hipError_t e = launch_normalize(p, B, K, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_normalize launch", e);
@@ -591,6 +628,7 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
 
 int ifd_onet_encode(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, int B, int Tmax, float* c, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_encode: not an ONet context");
     if (!sel || !c || B < 1 || Tmax < 1 || Tmax > 1024) return fail(ctx, IFD_ERR_ARG, "ifd_onet_encode: bad argument (1 <= Tmax <= 1024)");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -620,6 +658,7 @@ hipError_t onet_fold(ifd_ctx* ctx, const float* c, int B, hipStream_t s, float**
 
 int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, float* logits, float* dlogit_dp, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode: not an ONet context");
     if (!c || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -632,6 +671,7 @@ int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, 
 int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, const ifd_opt_params* prm,
                       const int32_t* loss_batch_per_cloud, float* m, float* v, float* loss, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: not an ONet context");
     if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 1024)");
@@ -667,6 +707,7 @@ int ifd_mc_table(int8_t* tri, uint8_t* ntri) {
 int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_params* prm, float* points,
                          int32_t* n_triangles, float* grid, float* triangles, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: not an ONet context");
     if (!c || !prm || prm->struct_size != (int32_t)sizeof(ifd_mesh_params) || !points || !n_triangles || B < 1)
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: bad argument");

@@ -16,6 +16,7 @@
 
 #include "ifd_device.h"
 #include "ifd_internal.h"
+#include "mc_table_data.h"
 
 namespace ifd {
 
@@ -200,10 +201,12 @@ hipError_t launch_mise_fill(const MiseGrid& g, int B, hipStream_t s) {
 //
 // Corner / edge numbering and the inside test (value <= isovalue) are the reference's (= Bourke's): corners 0..3 =
 // (0,0,0) (1,0,0) (1,1,0) (0,1,0), 4..7 the same at z + 1; edges 0-3 bottom ring, 4-7 top ring, 8-11 verticals.
-// Vertices are the linear iso-crossings of the grid edges, identical to the reference's.  The polygonisation table is
-// NOT the classic 256 x 16 table: it is generated at start-up (mc_build_table, host) by tracing, for every sign
-// configuration, the closed loops the iso-surface cuts out of the cube faces and fanning each loop - a
-// crack-free triangulation of the same vertex loops (ambiguous faces: the two inside corners are connected).
+// Vertices are the linear iso-crossings of the grid edges, identical to the reference's.  The polygonisation is the
+// reference's as well, triangle for triangle: kMcTriTable (mc_table_data.h) records what its compiled libmcubes emits for
+// each of the 256 sign configurations of a single cube - edge triples in its order and winding - obtained by running that
+// library (scripts/probe_mc_table.py; the classic Lorensen-Cline table in this file's numbering).  Round 1 generated its
+// own table by tracing the face loops and fanning them: the same vertices and triangle counts, but other diagonals in
+// the fans, i.e. a different (if equivalent) surface.
 // ---------------------------------------------------------------------------------------------
 struct McTable {
     int8_t tri[256][16];          // up to 5 triangles as edge triples, -1 terminated
@@ -211,57 +214,14 @@ struct McTable {
 };
 __constant__ McTable c_mc;
 
-static const int kEdgeCorner[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
-
-// Build the table on the host.  A face is a 4-cycle of corners; an inside/outside transition along a face edge is
-// an iso-crossing of that cube edge.  On every face the crossings are paired into segments (2 crossings: one segment;
-// 4 crossings - the ambiguous face - two segments that each cut off one OUTSIDE corner, i.e. the inside corners stay
-// connected).  Two faces share every cube edge and traverse it in opposite directions, so directed segments
-// (from the crossing that enters the inside set to the one that leaves it) chain head to tail into closed loops;
-// each loop is fanned from its first vertex.
 static void mc_build_table(McTable& T) {
-    // faces as corner 4-cycles, counter-clockwise seen from OUTSIDE the cube
-    static const int F[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {1, 2, 6, 5}, {3, 0, 4, 7}};
-    auto edge_of = [](int a, int b) {
-        for (int e = 0; e < 12; ++e)
-            if ((kEdgeCorner[e][0] == a && kEdgeCorner[e][1] == b) || (kEdgeCorner[e][0] == b && kEdgeCorner[e][1] == a)) return e;
-        return -1;
-    };
     for (int cfg = 0; cfg < 256; ++cfg) {
-        int nxt[12];
-        for (int e = 0; e < 12; ++e) nxt[e] = -1;
-        for (int f = 0; f < 6; ++f) {
-            int in[4];
-            for (int i = 0; i < 4; ++i) in[i] = (cfg >> F[f][i]) & 1;
-            int nin = in[0] + in[1] + in[2] + in[3];
-            if (nin == 0 || nin == 4) continue;
-            // crossings on face edge i (corner i -> corner i+1)
-            for (int i = 0; i < 4; ++i) {
-                const int j = (i + 1) & 3;
-                if (in[i] && !in[j]) {
-                    // leaving the inside at edge i: follow the outside run to where the inside is entered again
-                    int k = j;
-                    while (!in[(k + 1) & 3]) k = (k + 1) & 3;
-                    // entering at face edge k (corner k -> k+1)
-                    const int e_out = edge_of(F[f][i], F[f][j]), e_in = edge_of(F[f][k], F[f][(k + 1) & 3]);
-                    nxt[e_in] = e_out;
-                }
-            }
-        }
         int n = 0;
-        bool used[12] = {false};
-        for (int e0 = 0; e0 < 12; ++e0) {
-            if (nxt[e0] < 0 || used[e0]) continue;
-            int loop[12], len = 0;
-            for (int e = e0; !used[e]; e = nxt[e]) { used[e] = true; loop[len++] = e; }
-            for (int i = 1; i + 1 < len && n + 3 <= 15; ++i) {
-                T.tri[cfg][n++] = (int8_t)loop[0];
-                T.tri[cfg][n++] = (int8_t)loop[i];
-                T.tri[cfg][n++] = (int8_t)loop[i + 1];
-            }
+        for (int i = 0; i < 16; ++i) {
+            T.tri[cfg][i] = kMcTriTable[cfg][i];
+            if (i % 3 == 2 && kMcTriTable[cfg][i] >= 0) ++n;
         }
-        T.ntri[cfg] = (uint8_t)(n / 3);
-        for (; n < 16; ++n) T.tri[cfg][n] = -1;
+        T.ntri[cfg] = (uint8_t)n;
     }
 }
 

@@ -15,9 +15,15 @@
  *   - all array arguments are DEVICE pointers owned by the caller unless the
  *     name ends in _host.  float = IEEE binary32.  Arrays are dense, row-major.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
- *     are asynchronous with respect to the host; they never synchronise.
- *   - a context is bound to one device and may be used from one thread at a
- *     time; different contexts are independent (no hidden globals).
+ *     only enqueue work on it and return; the host blocks in: ifd_create /
+ *     ifd_onet_create / ifd_destroy, ifd_get_counters, ifd_onet_mesh_sample (one
+ *     stream synchronisation per MISE round), and in a call that needs more
+ *     context workspace than any earlier call on that context (a one-time
+ *     device synchronisation while the workspace grows).
+ *   - a context is bound to the device given to ifd_create: every entry point
+ *     makes that device current for the duration of the call and restores the
+ *     caller's (launches and workspace never land on another GPU).  One thread
+ *     at a time per context; different contexts are independent (no hidden globals).
  *
  * Plane layout used on the device ("channel-last"):
  *     planes[b][plane][row][col][ch],  plane in {0:xz, 1:xy, 2:yz}, row = u1 cell,
@@ -185,9 +191,10 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
  * failures served by the exact brute-force scan, [2] extra wave-level rebuild work (exact scans for the list
  * radii + re-passes for overflowed balls), [3] shader-clock cycles cloud 0 spent in the optimiser kernel
  * (effective clock = cycles / kernel time), [4] wave-steps that had to evaluate the back ring of the lists,
- * [5] wave-steps on the exact insertion path (near-ties, loss-reporting step), [6] wave-steps with individual
+ * [5] wave-steps with a near-tie settled by an exact per-point query (and the loss-reporting step), [6] wave-steps with individual
  * list refreshes, [7] lists built in total; of the most recent ifd_onet_mesh_sample: [8] grid points evaluated,
- * [9] MISE rounds (summed over chunks).  n <= IFD_N_COUNTERS. */
+ * [9] MISE rounds (summed over chunks).  n <= IFD_N_COUNTERS (slots beyond it exist only for the wave trace of
+ * diagnostic -DIFD_TRACE builds). */
 #define IFD_N_COUNTERS 16
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
 

@@ -63,13 +63,21 @@ def extract_mesh(value_grid: np.ndarray, thr: float, padding: float = 0.1):
     return vertices, triangles.astype(np.int64)
 
 
-def sample_surface(vertices: np.ndarray, faces: np.ndarray, count: int, rng: np.random.Generator) -> np.ndarray:
-    """trimesh.sample.sample_surface (remesh_defense.py:155-156), restated from its documentation."""
+def sample_surface(vertices: np.ndarray, faces: np.ndarray, count: int, rng: np.random.Generator = None,
+                   uniforms: np.ndarray = None) -> np.ndarray:
+    """trimesh.sample.sample_surface (remesh_defense.py:155-156), restated from its documentation: faces drawn with
+    probability proportional to their area (cumulative sum + searchsorted on `count` uniforms), then a uniform point of
+    the face from two more uniforms, reflected into the triangle when their sum exceeds one.  trimesh itself is not
+    installed here (parity against its code is unpinned); `uniforms` [count, 3] (face pick, two barycentric draws) makes
+    the restatement a deterministic function, which is what the GPU sampler is pinned against."""
     tri = vertices[faces]
     area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
     cum = np.cumsum(area)
-    face = np.searchsorted(cum, rng.random(count) * cum[-1])
-    r = rng.random((count, 2))
+    if uniforms is not None:
+        pick, r = np.asarray(uniforms[:, 0], np.float64), np.array(uniforms[:, 1:3], np.float64)
+    else:
+        pick, r = rng.random(count), rng.random((count, 2))
+    face = np.searchsorted(cum, pick * cum[-1])
     flip = r.sum(1) > 1
     r[flip] = 1 - r[flip]
     t = tri[face]

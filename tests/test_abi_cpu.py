@@ -104,10 +104,7 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt, f
 
 
-def test_marching_cubes_table_is_a_valid_polygonisation():
-    """The start-up generated table (ifd_mc_table): triangles only use edges the surface crosses, every crossed edge is
-    used, at most 5 triangles, and the segments left on each cube face are the same for both cubes sharing the face
-    (crack-free), whatever the configuration of the neighbour."""
+def _mc_table(lib=None):
     import ctypes as C
     import numpy as np
     from ifdefense_amd import _lib
@@ -115,38 +112,66 @@ def test_marching_cubes_table_is_a_valid_polygonisation():
     tri = np.zeros((256, 16), np.int8)
     ntri = np.zeros(256, np.uint8)
     assert lib.ifd_mc_table(tri.ctypes.data_as(C.c_void_p), ntri.ctypes.data_as(C.c_void_p)) == 0
-    EC = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
-    faces = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (3, 0, 4, 7)]
-    assert ntri.max() == 5 and ntri[0] == 0 and ntri[255] == 0
+    return tri, ntri
 
-    def face_segments(cfg, face):
-        fe = {frozenset((face[i], face[(i + 1) % 4])) for i in range(4)}
-        on_face = [e for e, (a, b) in enumerate(EC) if frozenset((a, b)) in fe]
-        segs = set()
-        for t in range(ntri[cfg]):
-            e3 = [int(x) for x in tri[cfg, 3 * t:3 * t + 3]]
-            for i in range(3):
-                a, b = e3[i], e3[(i + 1) % 3]
-                if a in on_face and b in on_face:
-                    s = frozenset((a, b))
-                    segs ^= {s}                      # interior fan diagonals lying in a face would cancel in pairs
-        return segs
 
+_EC = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+_CORNER = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+
+
+def test_marching_cubes_table_is_the_reference_polygonisation():
+    """ifd_mc_table == the fixture recorded from the reference's compiled libmcubes (scripts/probe_mc_table.py ->
+    tests/golden/mc_table_ref.npz): same triangles, same order, same winding, for all 256 sign configurations; plus the
+    structural facts any polygonisation must satisfy (only crossed edges, every crossed edge, at most 5 triangles)."""
+    import os
+    import numpy as np
+    tri, ntri = _mc_table()
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mc_table_ref.npz"))
+    assert np.array_equal(tri, ref["tri"]) and np.array_equal(ntri, ref["ntri"])
+    assert ntri.max() == 5 and ntri[0] == 0 and ntri[255] == 0 and int(ntri.sum()) == 820
     for cfg in range(256):
-        crossed = {e for e, (a, b) in enumerate(EC) if ((cfg >> a) & 1) != ((cfg >> b) & 1)}
+        crossed = {e for e, (a, b) in enumerate(_EC) if ((cfg >> a) & 1) != ((cfg >> b) & 1)}
         used = {int(x) for x in tri[cfg, :3 * ntri[cfg]]}
         assert used == crossed, cfg
         assert (tri[cfg, 3 * ntri[cfg]:] == -1).all()
-        # each face: the surface leaves exactly the segments the face rule prescribes (depends on the face's 4 signs only)
-        for face in faces:
-            signs = tuple((cfg >> c) & 1 for c in face)
-            n_cross = sum(signs[i] != signs[(i + 1) % 4] for i in range(4))
-            assert len(face_segments(cfg, face)) == n_cross // 2, (cfg, face)
-    # crack-freeness: the segments on a face are a function of that face's corner signs alone
-    seen = {}
+
+
+def test_marching_cubes_single_cubes_against_live_reference_library():
+    """Every sign configuration x random corner values through (ifd_mc_table + the iso-crossing interpolation) and through
+    the reference's own libmcubes (oracle/_ref): identical vertex coordinates in identical triangle order - the surface
+    is the reference's triangle for triangle, so triangle count, area and orientation (signed volume) agree exactly."""
+    import os
+    import sys
+    import numpy as np
+    import pytest
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    if not os.path.isdir(d) or not any(f.startswith("mcubes") for f in os.listdir(d)):
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py needs /root/reference)")
+    sys.path.insert(0, d)
+    import mcubes
+    tri, ntri = _mc_table()
+    rng = np.random.default_rng(7)
+    corner = np.array(_CORNER, float)
     for cfg in range(256):
-        for face in faces:
-            signs = tuple((cfg >> c) & 1 for c in face)
-            key = (face, signs)
-            segs = face_segments(cfg, face)
-            assert seen.setdefault(key, segs) == segs, (cfg, face)
+        for rep in range(3):
+            val = np.where([(cfg >> m) & 1 for m in range(8)], -1.0, 1.0) * rng.uniform(0.05, 1.0, 8)
+            if rep == 2:
+                val[rng.integers(0, 8)] = -0.0 if (cfg >> 0) & 1 else val[0]          # a corner exactly on the iso-value (inside: <=)
+                cfg_eff = sum(1 << m for m in range(8) if val[m] <= 0.0)
+            else:
+                cfg_eff = cfg
+            grid = np.empty((2, 2, 2))
+            for m in range(8):
+                grid[tuple(corner[m].astype(int))] = val[m]
+            v, t = mcubes.marching_cubes(grid, 0.0)
+            v = v - 0.5                                                          # mcubes.pyx's cell-centre shift
+            ours = []
+            for k in range(ntri[cfg_eff]):
+                for e in tri[cfg_eff, 3 * k:3 * k + 3]:
+                    a, b = _EC[e]
+                    w = 0.5 if val[b] == val[a] else (0.0 - val[a]) / (val[b] - val[a])     # marchingcubes.cpp:290-297
+                    ours.append(corner[a] + (corner[b] - corner[a]) * w)
+            ours = np.array(ours).reshape(-1, 3, 3)
+            theirs = v[t.astype(int)] if len(t) else np.zeros((0, 3, 3))
+            assert ours.shape == theirs.shape, (cfg, rep)
+            np.testing.assert_allclose(ours, theirs, rtol=0, atol=1e-12, err_msg=str((cfg, rep)))
