@@ -9,11 +9,11 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- \
-    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for set in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum"; do
     name=${set%%:*}; ctr=${set#*:}
     timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o $name -- \
-        python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/$name.err
+        python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/$name.err
 done
 # calibration of FETCH_SIZE on the decoder tile's gather pattern (a known byte count, every 128-byte line once)
 if [ -x $R/scripts/gather_calib ]; then

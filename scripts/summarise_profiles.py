@@ -20,7 +20,7 @@ if f:
     with open(os.path.join(out, "%s_bench_kernel_stats.csv" % tag), "w") as o:
         o.write(open(f).read())
     for r in rows:
-        if "optimize_kernel" in r["Name"]:
+        if "optimize_kernel" in r["Name"] and "onet" not in r["Name"]:
             res["optimize_kernel_calls"] = int(r["Calls"])
             res["optimize_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
             res["optimize_kernel_share_pct"] = float(r["Percentage"])
@@ -31,9 +31,9 @@ def pmc(sub):
     acc = {}
     if f:
         for r in csv.DictReader(open(f)):
-            if "optimize_kernel" in r["Kernel_Name"]:
+            if "optimize_kernel" in r["Kernel_Name"] and "onet" not in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-        keep = [r for r in csv.DictReader(open(f)) if "optimize_kernel" in r["Kernel_Name"]]
+        keep = [r for r in csv.DictReader(open(f)) if "optimize_kernel" in r["Kernel_Name"] and "onet" not in r["Kernel_Name"]]
         if keep:
             with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, sub)), "w", newline="") as o:
                 w = csv.DictWriter(o, fieldnames=list(keep[0].keys()))
