@@ -218,8 +218,32 @@ def main(argv=None, model="convonet", restorer_factory=None, backend=None, devic
         if bad:
             raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
 
-    for one in files:
-        one_file(one)
+    if len(files) > 1 and not args.train:
+        # a directory of files (opt_defense.py:380-385): one stream of device passes - the SOR / preprocess / encoder
+        # kernels of file n + 1 run on a second HIP stream under the tail of file n's optimiser (pipeline.defend_stream),
+        # and under rank 0's device-to-host copy and np.savez of file n
+        from . import defend_stream, get_save_name
+        from .dist import gather_shards, shard_range
+        arrays = [np.load(f)['test_pc'][..., :3] for f in files]
+        ranges = [shard_range(len(a), rank, world) for a in arrays]
+        shards = [a[lo:hi] for a, (lo, hi, per) in zip(arrays, ranges)]
+        stream = defend_stream(r, shards, dargs, bases=[lo for lo, hi, per in ranges], totals=[len(a) for a in arrays])
+        for path, a, (lo, hi, per), local_out in zip(files, arrays, ranges, stream):
+            err = None
+            try:
+                out = gather_shards(local_out, len(a), per).cpu().numpy()
+                if rank == 0:
+                    defend_npz_test_data(r, path, dargs, defend=lambda pc, out=out: out)
+            except Exception as e:              # noqa: BLE001
+                err = e
+            bad = D.any_rank_failed(err is not None, device)
+            if err is not None:
+                raise SystemExit("rank %d failed on %s: %s: %s" % (rank, path, type(err).__name__, err))
+            if bad:
+                raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
+    else:
+        for one in files:
+            one_file(one)
     D.shutdown()
     return 0
 

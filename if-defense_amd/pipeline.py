@@ -33,6 +33,83 @@ class DefenseArgs:
     seed: int = 0                   # extension: the reference is unseeded
     chunk: int = 4096               # extension: clouds per device pass (memory knob, ~17 MB of scratch per cloud;
                                     # does not change results)
+    printing: bool = False          # optimize_points(..., printing=True) of the reference (opt_defense.py:229-236)
+
+
+def _prepare_unit(r: Restorer, xb: torch.Tensor, args: DefenseArgs, base: int, total: int):
+    """SOR -> preprocess / subset / init -> encoder for one device pass (opt_defense.py:262-306), on the CURRENT stream.
+    Returns what the optimiser needs: (init points, planes, per-cloud 1/B group sizes)."""
+    keep = r.sor(xb, args.sor_k, args.sor_alpha) if args.sor else None
+    prep = r.prepare(xb, keep, n_sel=args.input_npoint, n_opt=args.sample_npoint, padding_scale=args.padding_scale,
+                     init_sigma=args.init_sigma, seed=args.seed, cloud_index_base=base)
+    planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+    # the 1/B of both losses is the size of the reference batch each cloud would have been in
+    bs = int(args.batch_size)
+    gidx = torch.arange(base, base + xb.shape[0], device=r.device)
+    start = (gidx // bs) * bs
+    lb = torch.clamp(total - start, max=bs).to(torch.int32)
+    return prep["init"], planes, lb
+
+
+def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=None, overlap: bool = True):
+    """Restore a SEQUENCE of arrays (the files of a --data_root directory, the steps of a benchmark), yielding one
+    restored device tensor [N_i, sample_npoint, 3] per array, in order.
+
+    The optimiser kernel keeps one workgroup per CU busy for ~0.9 s per 2468 clouds, and its last round leaves a third
+    of the CUs idle (2468 = 9.64 x 256).  With ``overlap`` the SOR / preprocess / encoder kernels of the NEXT device pass
+    are enqueued on a second HIP stream as soon as the current pass's optimiser is launched, so they run on the CUs that
+    the tail frees instead of after it.  Results are bit-identical to the serial order: every kernel is deterministic and
+    the passes share nothing but read-only weights (the context's encoder scratch is used by one pass at a time: the
+    side stream's work is ordered, and the optimiser uses the separate neighbour-list scratch).
+    """
+    arrays = list(arrays)
+    n_arr = len(arrays)
+    bases = [0] * n_arr if bases is None else list(bases)
+    totals = [None] * n_arr if totals is None else list(totals)
+    units = []                                    # (array index, lo, hi): one device pass each
+    xs = []
+    for i, pc in enumerate(arrays):
+        x = torch.as_tensor(pc)[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
+        xs.append(x)
+        for lo in range(0, max(x.shape[0], 1), int(args.chunk)):
+            units.append((i, lo, min(x.shape[0], lo + int(args.chunk))))
+    outs = [torch.empty(x.shape[0], args.sample_npoint, 3, device=r.device, dtype=torch.float32) for x in xs]
+    on_gpu = torch.device(r.device).type == "cuda"           # (the host tests drive this with a stand-in model on the CPU)
+    main = torch.cuda.current_stream(r.device) if on_gpu else None
+    side = torch.cuda.Stream(r.device) if (on_gpu and overlap and len(units) > 1) else None
+    if side is not None:
+        side.wait_stream(main)                    # the inputs are resident; from here on the side stream only follows itself
+
+    def launch_prepare(u):
+        i, lo, hi = u
+        total = int(totals[i] if totals[i] is not None else bases[i] + xs[i].shape[0])
+        if hi <= lo:
+            return None
+        if side is None:
+            return _prepare_unit(r, xs[i][lo:hi], args, bases[i] + lo, total) + (None,)
+        with torch.cuda.stream(side):             # (side-stream order keeps the passes' use of the encoder scratch apart)
+            init, planes, lb = _prepare_unit(r, xs[i][lo:hi], args, bases[i] + lo, total)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in (init, planes, lb):              # consumed on the main stream: keep the allocator from recycling them early
+            t.record_stream(main)
+        return init, planes, lb, ev
+
+    ready = launch_prepare(units[0]) if units else None
+    done = 0
+    for k, (i, lo, hi) in enumerate(units):
+        cur = ready
+        if cur is not None:
+            init, planes, lb, ev = cur
+            if ev is not None:
+                main.wait_event(ev)
+            outs[i][lo:hi] = r.optimize_points(init, planes, rep_weight=args.rep_weight, iterations=args.iterations,
+                                               lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing)
+        ready = launch_prepare(units[k + 1]) if k + 1 < len(units) else None       # rides on the optimiser's tail
+        del cur
+        while done < n_arr and (k + 1 == len(units) or units[k + 1][0] > done):
+            yield outs[done]
+            done += 1
 
 
 def defend_point_cloud(r: Restorer, pc, args: DefenseArgs, cloud_index_base: int = 0, total_clouds: Optional[int] = None,
@@ -44,25 +121,7 @@ def defend_point_cloud(r: Restorer, pc, args: DefenseArgs, cloud_index_base: int
     reference batch (size ``batch_size``, the last one shorter) the cloud would have been in - so any sharding
     gives bit-identical results.
     """
-    x = torch.as_tensor(pc)[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
-    N = x.shape[0]
-    total = int(total_clouds if total_clouds is not None else cloud_index_base + N)
-    out = torch.empty(N, args.sample_npoint, 3, device=r.device, dtype=torch.float32)
-    bs = int(args.batch_size)
-    for lo in range(0, N, int(args.chunk)):
-        hi = min(N, lo + int(args.chunk))
-        xb = x[lo:hi]
-        keep = r.sor(xb, args.sor_k, args.sor_alpha) if args.sor else None
-        prep = r.prepare(xb, keep, n_sel=args.input_npoint, n_opt=args.sample_npoint, padding_scale=args.padding_scale,
-                         init_sigma=args.init_sigma, seed=args.seed, cloud_index_base=cloud_index_base + lo)
-        planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
-        # the 1/B of both losses is the size of the reference batch each cloud would have been in
-        gidx = torch.arange(cloud_index_base + lo, cloud_index_base + hi, device=r.device)
-        start = (gidx // bs) * bs
-        lb = torch.clamp(total - start, max=bs).to(torch.int32)
-        out[lo:hi] = r.optimize_points(prep["init"], planes, rep_weight=args.rep_weight, iterations=args.iterations,
-                                       lr=args.lr, loss_batch=lb, normalize=True)
-        del planes, prep
+    out = next(defend_stream(r, [pc], args, [cloud_index_base], [total_clouds]))
     return out if return_device else out.cpu().numpy()
 
 

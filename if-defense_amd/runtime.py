@@ -195,7 +195,7 @@ class Restorer:
                         lr: float = 1e-3, loss_batch=None, normalize: bool = True,
                         state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
                         return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
-                        knn_scan_every_step: bool = False):
+                        knn_scan_every_step: bool = False, printing: bool = False):
         """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
@@ -204,6 +204,9 @@ class Restorer:
         Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
         is left to the caller.
         """
+        if printing and state is None and not return_state and not return_loss:
+            return self._optimize_points_printing(opt_points, c, rep_weight, int(iterations) + 1 if steps is None else int(steps),
+                                                  lr, loss_batch, normalize, knn_scan_every_step)
         planes = self._cond(c)
         p = _f32(opt_points, self.device).clone()
         B, K = p.shape[:2]
@@ -234,6 +237,36 @@ class Restorer:
         if return_loss:
             out += (loss,)
         return out if len(out) > 1 else p
+
+    def _optimize_points_printing(self, opt_points, c, rep_weight, n_steps, lr, loss_batch, normalize, scan):
+        """printing=True of the reference's optimize_points (opt_defense.py:229-236): the losses of iterations 0, 100,
+        200, ... are printed.  The run is cut into segments that END on those iterations (the kernel reports the losses of
+        a launch's last step) and carries the Adam state across; the result is bit-identical to the uncut run (the
+        neighbour lists are exact at every step, the moments are passed on as they are)."""
+        p, st, t = opt_points, None, 0
+        B = opt_points.shape[0]
+        lb_mean = None
+        while t < n_steps:
+            seg = 1 if t == 0 else min(100, n_steps - t)
+            last = t + seg == n_steps
+            res = self.optimize_points(p, c, rep_weight=rep_weight, steps=seg, lr=lr, loss_batch=loss_batch,
+                                       normalize=normalize and last, state=st, return_state=True, return_loss=True,
+                                       knn_scan_every_step=scan)
+            p, st, loss = res
+            t += seg
+            it = t - 1
+            if it % 100 == 0:
+                l = loss.double().cpu()
+                if torch.is_tensor(loss_batch):
+                    lbv = loss_batch.double().cpu()
+                else:
+                    lbv = torch.full((B,), float(loss_batch or B), dtype=torch.float64)
+                # per-cloud terms carry their own 1/B; the reference's scalars are sums over the batch of B clouds
+                occ = float((l[:, 0]).sum()) * float(B) / float(lbv.sum()) if lbv.numel() else 0.0
+                rep = float(l[:, 1].mean()) * rep_weight
+                print('iter {}, loss {:.4f}'.format(it, occ + rep))
+                print('occ loss: {:.4f}, rep loss: {:.4f}'.format(occ, rep))
+        return p
 
     def counters(self) -> Dict[str, int]:
         """Diagnostic counters of the last optimize_points call (synchronises)."""

@@ -926,6 +926,25 @@ def test_onet_mesh_sampler_is_the_documented_algorithm_on_its_own_uniforms(onet,
         assert (d > 1e-5).sum() <= 2, (b, int((d > 1e-5).sum()))
 
 
+def test_streamed_driver_equals_serial_passes(restorer, golden):
+    """pipeline.defend_stream (pre-processing of pass n + 1 on a second HIP stream under pass n's optimiser) returns,
+    array by array, exactly what one defend_point_cloud call per array returns - also with a chunk size that cuts the
+    arrays into several device passes."""
+    import bench
+    import ifdefense_amd as I
+    arrays = [bench.synth_clouds(5, seed=40), golden["raw"], bench.synth_clouds(3, seed=41)]
+    bases = [0, 7, 100]
+    for chunk in (4096, 2):
+        args = I.DefenseArgs(iterations=12, batch_size=3, seed=3, chunk=chunk)
+        serial = [I.defend_point_cloud(restorer, a, args, cloud_index_base=b, total_clouds=b + len(a), return_device=True)
+                  for a, b in zip(arrays, bases)]
+        streamed = [o.clone() for o in I.defend_stream(restorer, arrays, args, bases=bases,
+                                                       totals=[b + len(a) for a, b in zip(arrays, bases)])]
+        assert len(streamed) == 3
+        for s_, t_ in zip(serial, streamed):
+            assert torch.equal(s_, t_)
+
+
 def test_lists_equal_scan_on_mixed_inputs(restorer):
     """Regression net for the neighbour lists (exact ties, refreshes, ragged K): a slice of scripts/fuzz_lists_vs_scan.py."""
     import bench

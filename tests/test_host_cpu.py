@@ -190,7 +190,7 @@ class FakeRestorer:
     def encode_inputs(self, sel, t):
         return sel.sum(dim=(1, 2))
 
-    def optimize_points(self, init, planes, rep_weight, iterations, lr, loss_batch, normalize):
+    def optimize_points(self, init, planes, rep_weight, iterations, lr, loss_batch, normalize, **kw):
         return init + planes[:, None, None] * 1e-3 + loss_batch.float()[:, None, None] * 1e-2 + iterations
 
 
@@ -242,6 +242,19 @@ def test_cli_sharded_write_uneven_split_empty_shards_and_train_path(tmp_path):
         outs[world] = {n: dict(np.load(tmp_path / "ConvONet-Opt" / ("convonet_opt-" + n))) for n in ("adv.npz", "two.npz", "tt.npz")}
         for n in ("adv.npz", "two.npz", "tt.npz"):
             os.remove(tmp_path / "ConvONet-Opt" / ("convonet_opt-" + n))
+    # a directory of files goes through the streamed driver (defend_stream): same files as one by one, at any world size
+    d = tmp_path / "dir"
+    d.mkdir()
+    np.savez(d / "adv.npz", test_pc=pc7, test_label=np.arange(7), target_label=np.arange(7)[::-1].copy())
+    np.savez(d / "two.npz", test_pc=pc2, test_label=np.array([3, 4]))
+    for world in (1, 2):
+        _run_cli(tmp_path, world, ["--data_root", str(d)] + flags)
+        for n in ("adv.npz", "two.npz"):
+            got = dict(np.load(d / "ConvONet-Opt" / ("convonet_opt-" + n)))
+            for k in outs[1][n]:
+                assert np.array_equal(got[k], outs[1][n][k]), (world, n, k)
+            os.remove(d / "ConvONet-Opt" / ("convonet_opt-" + n))
+        os.rmdir(d / "ConvONet-Opt")
     one = outs[1]
     assert sorted(one["adv.npz"]) == ["target_label", "test_label", "test_pc"]
     assert one["adv.npz"]["test_pc"].shape == (7, 16, 3) and one["adv.npz"]["test_pc"].dtype == np.float32
