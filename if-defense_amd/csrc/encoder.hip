@@ -5,12 +5,13 @@
 // One workgroup per cloud, one thread per input point (T <= 1024), everything between the xyz read and the
 // plane write stays in LDS / registers:
 //   * pool_local (pointnet.py:104-122) never materialises the [32,4096] scatter_max grids: a point's pooled
-//     feature is the channel-wise max over the points that share its cell, found by scanning the cell ids of
-//     the cloud held in LDS (cells are sparsely occupied: ~600 points over ~1700 occupied cells).
+//     feature is the channel-wise max over the points that share its cell, reached through a per-plane ring of
+//     the cell's points built once per cloud (cells are sparsely occupied: ~600 points over ~1700 occupied cells).
 //   * scatter_mean (pointnet.py:75-80) is evaluated gather-side in ascending point order by the first point
 //     of each cell: deterministic (no float atomics) and the same summation order as an index-ordered
 //     scatter_add.  The plane buffer must be zero-filled by the caller (empty cells stay 0).
-//   * the weights are wave-uniform -> scalar loads + SGPR-operand FMAs, no LDS traffic.
+//   * the weights are wave-uniform -> scalar loads + SGPR-operand FMAs, no LDS traffic.  (Staging each block's 20 KB
+//     of weights in LDS and reading them back with uniform-address loads was measured: 5.4 ms against 3.6 ms.)
 #include "ifd_device.h"
 #include "ifd_internal.h"
 
@@ -18,7 +19,7 @@ namespace ifd {
 
 constexpr int NET_STRIDE = 33;          // LDS row stride of the [T][32] feature matrix (bank-conflict pad)
 
-// out[o] = b[o] + sum_k W[o][k] * in[k]   (W row-major [NOUT][NIN], wave-uniform)
+// out[o] = b[o] + sum_k W[o][k] * in[k]   (W row-major [NOUT][NIN], uniform address -> s_load)
 template <int NOUT, int NIN, bool RELU_IN, bool HAS_BIAS>
 __device__ __forceinline__ void linear(const float* __restrict__ W, const float* __restrict__ b, const float (&in)[NIN],
                                        float (&out)[NOUT]) {
@@ -42,6 +43,10 @@ __device__ __forceinline__ void resnet_block(const float* __restrict__ w, const 
     for (int o = 0; o < 32; ++o) out[o] = xs[o] + dx[o];
 }
 
+// [threads][33] features + [3][threads] cell rings; the ring construction's scratch (head table int[4096] + unordered
+// chains u16[3][threads] = 22,528 B at 1024 threads) aliases the feature matrix, which is first written after it
+constexpr size_t enc_lds(int threads) { return (size_t)threads * NET_STRIDE * 4 + 3 * (size_t)threads * 2; }   // 141,312 B @1024
+
 template <int ENC_THREADS>
 __global__ __launch_bounds__(ENC_THREADS) void encode_points_kernel(const float* __restrict__ w, EncPointOffsets eo,
                                                                      const float* __restrict__ sel,
@@ -50,7 +55,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_points_kernel(const float*
                                                                      float* __restrict__ c_out, DecConst dc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* net = smem;                                                     // [ENC_THREADS][NET_STRIDE]
-    unsigned short* cell = reinterpret_cast<unsigned short*>(net + ENC_THREADS * NET_STRIDE);   // [3][ENC_THREADS]
+    unsigned short* ring = reinterpret_cast<unsigned short*>(net + ENC_THREADS * NET_STRIDE);
+                                                                           // [3][ENC_THREADS] next point of my cell
 
     const int b = blockIdx.x, i = threadIdx.x;
     const int T = t_per_cloud ? min(t_per_cloud[b], Tmax) : Tmax;
@@ -67,9 +73,40 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_points_kernel(const float*
         if (u < 0.f) u = 0.f;
         ci[a] = (int)(u * (float)RES);
     }
-    int mycell[3] = {ci[0] + RES * ci[2], ci[0] + RES * ci[1], ci[1] + RES * ci[2]};   // xz, xy, yz
+    const int mycell[3] = {ci[0] + RES * ci[2], ci[0] + RES * ci[1], ci[1] + RES * ci[2]};   // xz, xy, yz
+
+    // ---- the points of a cell as a ring in ascending point order (per plane) ----------------------------------
+    // Both pool_local and scatter_mean only ever combine the points that share a cell (~600 points over ~1700
+    // occupied cells of 4096), so the cloud's cell structure is resolved ONCE: an exchange on the cell's head
+    // slot chains the points of a cell in arrival order, the oldest closes the chain into a ring, and every point
+    // then picks its ascending successor (smallest larger index, else the ring's smallest).  The result does not
+    // depend on the arrival order.  (Round 1 re-scanned the cloud's 600 cell ids in each of the four pooling
+    // stages and again for the mean: 13 of the kernel's 16 ms.)
+    {
+        int* head = reinterpret_cast<int*>(net);                                           // [RES*RES] (aliases net)
+        unsigned short* chain = reinterpret_cast<unsigned short*>(head + RES * RES);       // [3][ENC_THREADS]
 #pragma unroll
-    for (int P = 0; P < 3; ++P) cell[P * ENC_THREADS + i] = live ? (unsigned short)mycell[P] : (unsigned short)0xffff;
+        for (int P = 0; P < 3; ++P) {
+            for (int k = i; k < RES * RES; k += ENC_THREADS) head[k] = -1;
+            __syncthreads();
+            int prev = -1;
+            if (live) prev = atomicExch(&head[mycell[P]], i);
+            __syncthreads();
+            chain[P * ENC_THREADS + i] = (unsigned short)(!live ? i : prev >= 0 ? prev : head[mycell[P]]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            const unsigned short* ch = chain + P * ENC_THREADS;
+            int mn = i, up = 0x7fffffff;
+            for (int j = ch[i]; j != i; j = ch[j]) {
+                mn = min(mn, j);
+                if (j > i) up = min(up, j);
+            }
+            ring[P * ENC_THREADS + i] = (unsigned short)(up != 0x7fffffff ? up : mn);
+        }
+        __syncthreads();
+    }
 
     float x[64], cur[32];
     linear<64, 3, false, true>(w + eo.pos_w, w + eo.pos_b, p, x);          // fc_pos
@@ -79,27 +116,22 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_points_kernel(const float*
     __syncthreads();
 
     for (int blk = 1; blk < 5; ++blk) {
-        // pool_local: sum over planes of (max over the points of my cell), self included
+        // pool_local (pointnet.py:104-122): sum over planes of (max over the points of my cell), self included
         float pooled[32];
 #pragma unroll
         for (int o = 0; o < 32; ++o) pooled[o] = 0.f;
-        if (live) {
 #pragma unroll 1
-            for (int P = 0; P < 3; ++P) {
-                float mx[32];
+        for (int P = 0; P < 3; ++P) {
+            float mx[32];
 #pragma unroll
-                for (int o = 0; o < 32; ++o) mx[o] = cur[o];
-                const unsigned short mc = (unsigned short)mycell[P];
-                const unsigned short* cp = cell + P * ENC_THREADS;
-                for (int j = 0; j < T; ++j) {
-                    if (cp[j] == mc && j != i) {
+            for (int o = 0; o < 32; ++o) mx[o] = cur[o];
+            const unsigned short* rp = ring + P * ENC_THREADS;
+            for (int j = rp[i]; j != i; j = rp[j]) {
 #pragma unroll
-                        for (int o = 0; o < 32; ++o) mx[o] = fmaxf(mx[o], net[j * NET_STRIDE + o]);
-                    }
-                }
-#pragma unroll
-                for (int o = 0; o < 32; ++o) pooled[o] += mx[o];
+                for (int o = 0; o < 32; ++o) mx[o] = fmaxf(mx[o], net[j * NET_STRIDE + o]);
             }
+#pragma unroll
+            for (int o = 0; o < 32; ++o) pooled[o] += mx[o];
         }
 #pragma unroll
         for (int o = 0; o < 32; ++o) { x[o] = cur[o]; x[32 + o] = pooled[o]; }    // torch.cat([net, pooled], dim=2)
@@ -122,26 +154,25 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_points_kernel(const float*
     }
     __syncthreads();
 
-    // scatter_mean into the zero-filled channel-last planes, written by the first point of every cell
+    // scatter_mean into the zero-filled channel-last planes: the first point of a cell walks its ring, which adds the
+    // cell's features in ascending point order (the order of an index-ordered scatter_add); later points of the cell
+    // meet a smaller index on their first wrap and drop out
     if (live) {
-#pragma unroll 1
+#pragma unroll
         for (int P = 0; P < 3; ++P) {
-            const unsigned short mc = (unsigned short)mycell[P];
-            const unsigned short* cp = cell + P * ENC_THREADS;
+            const unsigned short* rp = ring + P * ENC_THREADS;
+            float sum[32];
+#pragma unroll
+            for (int o = 0; o < 32; ++o) sum[o] = c[o];
+            float cnt = 1.f;
             bool first = true;
-            for (int j = 0; j < i; ++j) first = first && (cp[j] != mc);
+            for (int j = rp[i]; j != i; j = rp[j]) {
+                if (j < i) { first = false; break; }
+                cnt += 1.f;
+#pragma unroll
+                for (int o = 0; o < 32; ++o) sum[o] += net[j * NET_STRIDE + o];
+            }
             if (first) {
-                float sum[32];
-#pragma unroll
-                for (int o = 0; o < 32; ++o) sum[o] = c[o];
-                float cnt = 1.f;
-                for (int j = i + 1; j < T; ++j) {
-                    if (cp[j] == mc) {
-                        cnt += 1.f;
-#pragma unroll
-                        for (int o = 0; o < 32; ++o) sum[o] += net[j * NET_STRIDE + o];
-                    }
-                }
                 float* dst = planes + (((size_t)b * 3 + P) * RES * RES + mycell[P]) * CH;
 #pragma unroll
                 for (int o = 0; o < 32; o += 4)
@@ -151,8 +182,6 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_points_kernel(const float*
         }
     }
 }
-
-constexpr size_t enc_lds(int threads) { return (size_t)threads * NET_STRIDE * 4 + 3 * (size_t)threads * 2; }   // 141,312 B @1024
 
 hipError_t configure_encoder_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_points_kernel<640>),

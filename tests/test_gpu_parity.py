@@ -344,6 +344,29 @@ def test_encoder_ragged_matches_dense(restorer, golden):
     assert torch.equal(a[1], b[0])
 
 
+def test_encoder_point_half_against_oracle_large_and_crowded(restorer, oracle_weights):
+    """encode_points against the oracle beyond the golden clouds: a 1000-point subset (the 1024-thread / 160 KB LDS
+    configuration) and clouds whose points crowd into a few cells (cell rings of tens to hundreds of points, several
+    points per cell in every plane) - the ring construction, the pooled max and the ascending-order mean."""
+    from oracle import convonet_oracle as O
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "T1000": torch.rand(2, 1000, 3, generator=g) - 0.5,
+        "crowded600": torch.cat([0.02 * torch.randn(1, 600, 3, generator=g),                     # ~5 x 5 cells
+                                 torch.zeros(1, 600, 3) + 0.3], 0),                              # all in ONE cell
+        "clusters640": (torch.randint(0, 6, (2, 640, 3), generator=g).float() / 6 - 0.4),        # <= 216 distinct points
+    }
+    for name, sel in cases.items():
+        pre, c = restorer.encode_points(sel, want_c=True)
+        c_ref, index = O.pointnet_features(oracle_weights, sel)
+        assert _rel(c.cpu().numpy(), c_ref.numpy()) < 2e-5, name
+        for i, pl in enumerate(PL):
+            ref = O.scatter_mean_plane(c_ref, index[pl]).numpy()                                  # [B,32,64,64]
+            got = pre[:, i].permute(0, 3, 1, 2).cpu().numpy()
+            assert ((got != 0).any(1) == (ref != 0).any(1)).all(), (name, pl)
+            assert _rel(got, ref) < 2e-5, (name, pl)
+
+
 def test_defend_point_cloud_end_to_end_and_sharding(restorer, golden):
     import ifdefense_amd as I
     args = I.DefenseArgs(iterations=30, batch_size=3, seed=3)
