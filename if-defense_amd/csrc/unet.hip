@@ -37,7 +37,7 @@ struct ConvArgs {
 // PG pixel groups (stacked vertically) x CG groups of 32 output channels.  KS: 3 (pad 1) or 1.
 // UP: ConvTranspose2d(k=2,s=2): blockIdx.y additionally enumerates the 4 (dy,dx) taps.
 template <int TW, int PG, int CG, int KS, bool UP>
-__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 96 VGPRs: five blocks (20 waves) per CU
     constexpr int RW = 32 / TW;                 // rows per wave
     constexpr int TH = PG * RW;                 // tile height
     constexpr int HALO = KS / 2;
@@ -66,31 +66,56 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     const int m = lane & 31, kh = lane >> 5;
     const int py = pg * RW + m / TW, px = m % TW;                      // pixel of this lane inside the tile
 
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
+    // Global -> register -> LDS staging, one chunk ahead: the loads of chunk c+1 are issued before the MFMAs of chunk c
+    // and land in registers under them; after the barrier they are written to LDS.  (Round 1 staged inside the chunk,
+    // one load per loop iteration with a full vmcnt(0) wait each: ~8 serial L2 round trips per chunk in front of 72 MFMAs.)
+    // (Walking several tiles per block with the look-ahead running across the tile boundary was measured too: the
+    // longer live ranges cost registers / occupancy, 82.5 ms against 74.0 ms for the whole U-Net.)
+    constexpr int IN_N = LH * LW * (CK / 4), IN_IT = (IN_N + 255) / 256;      // f32x4 loads of the pixel tile per thread
+    constexpr int W_N = TAPS * CK * (NCO / 4), W_IT = (W_N + 255) / 256;      // ... of the weight slab
+    f32x4 rin[IN_IT], rw[W_IT];
+    auto fetch = [&](int c0) {
         const float* src = c0 < a.C0 ? a.in0 : a.in1;
         const int cs = c0 < a.C0 ? a.C0 : a.C1;                        // channel count of the source tensor
         const int cl = c0 < a.C0 ? c0 : c0 - a.C0;                     // channel offset inside it
-        __syncthreads();
-        // ---- stage the (TH+2)x(TW+2) pixel tile, 16 channels, zero outside the image -----------------------
-        for (int i = tid; i < LH * LW * (CK / 4); i += 256) {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {                           // (TH+2)x(TW+2) pixel tile, 16 channels, zero outside
+            const int i = tid + it * 256;
             const int q4 = i % (CK / 4), pix = i / (CK / 4);
             const int ly = pix / LW, lx = pix % LW;
             const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * a.H + gy) * a.W + gx) * cs + cl + 4 * q4);
-            float* d = s_in + pix * CKP + 4 * q4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            rin[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((IN_N % 256 == 0 || i < IN_N) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                rin[it] = *reinterpret_cast<const f32x4*>(src + (((size_t)n * a.H + gy) * a.W + gx) * cs + cl + 4 * q4);
         }
-        // ---- stage the weight slab [taps][16][NCO] -------------------------------------------------------------
-        for (int i = tid; i < TAPS * CK * (NCO / 4); i += 256) {
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {                            // weight slab [taps][16][NCO]
+            const int i = tid + it * 256;
             const int q4 = i % (NCO / 4), row = i / (NCO / 4);         // row = tap * CK + k
             const int tap = row / CK, k = row % CK;
             const int gtap = UP ? uptap : tap;
-            *reinterpret_cast<f32x4*>(s_w + row * NCO + 4 * q4) =
-                *reinterpret_cast<const f32x4*>(a.w + ((size_t)gtap * Cin + c0 + k) * a.Cout + co0 + 4 * q4);
+            if (W_N % 256 == 0 || i < W_N)
+                rw[it] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)gtap * Cin + c0 + k) * a.Cout + co0 + 4 * q4);
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+        __syncthreads();                                               // the previous chunk's MFMAs have read the LDS tiles
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            if (IN_N % 256 == 0 || i < IN_N) {
+                float* d = s_in + (i / (CK / 4)) * CKP + 4 * (i % (CK / 4));
+                d[0] = rin[it].x; d[1] = rin[it].y; d[2] = rin[it].z; d[3] = rin[it].w;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            if (W_N % 256 == 0 || i < W_N) *reinterpret_cast<f32x4*>(s_w + 4 * i) = rw[it];
         }
         __syncthreads();
+        if (c0 + CK < Cin) fetch(c0 + CK);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = tap / KS, dx = tap % KS;
