@@ -31,12 +31,19 @@ struct ConvArgs {
     float* pool_out;       // [N][H/2][W/2][Cout] or nullptr
     int H, W, C0, C1, Cout;
     int relu;
+    const float* fuse_w;   // FUSE: [Cout][32] weights of a 1x1 convolution applied to this layer's output (conv_final)
+    const float* fuse_b;   // FUSE: its bias [32]; a.out then receives the 1x1 convolution's result
 };
 
 // TW: tile width in pixels (16 or 8); a wave covers 32/TW rows x TW columns.  PG x CG = 4 waves:
 // PG pixel groups (stacked vertically) x CG groups of 32 output channels.  KS: 3 (pad 1) or 1.
 // UP: ConvTranspose2d(k=2,s=2): blockIdx.y additionally enumerates the 4 (dy,dx) taps.
-template <int TW, int PG, int CG, int KS, bool UP>
+// FUSE (Cout = 32, CG = 1): a following conv1x1 (32 -> 32, bias, no ReLU: conv_final, unet.py:238) is applied to the
+// block's activated tile before it leaves the CU - the tile goes through LDS once to turn the accumulator layout
+// (lane = channel) into the A-operand layout (lane = pixel), 16 more MFMAs per wave, and the intermediate tensor is
+// neither written nor read back (the stand-alone 1x1 kernel was HBM-bound: 1.4 ms at 45 TFLOP/s).  Same MFMA sequence
+// over the 32 channels as the stand-alone kernel -> bit-identical results.
+template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false>
 __global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 96 VGPRs: five blocks (20 waves) per CU
     constexpr int RW = 32 / TW;                 // rows per wave
     constexpr int TH = PG * RW;                 // tile height
@@ -136,6 +143,27 @@ __global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 
         v[r] = acc[r] + bv;
         if (a.relu) v[r] = fmaxf(v[r], 0.f);
     }
+    if constexpr (FUSE) {
+        static_assert(CG == 1 && !UP && TAPS * CK * NCO >= 128 * 33, "FUSE: one 32-channel group, tile fits the weight slab");
+        __syncthreads();                                               // every wave is done with the weight slab
+        float* T = s_w + wave * 32 * 33;                               // [32 pixels of this wave][33]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + m] = v[r];
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        const float* fw = a.fuse_w + kh * 32 + m;                      // B[k = channel][n = output channel]
+        float bw[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bw[ks] = fw[2 * ks * 32];
+        // (wave-private rows of T: no workgroup barrier needed between the writes above and these reads)
+        const float* tp = T + m * 33 + kh;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tp[2 * ks], bw[ks], acc2, 0, 0, 0);
+        const float fb = a.fuse_b[m];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc2[r] + fb;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mm = (r & 3) + 8 * (r >> 2) + 4 * kh;               // pixel index inside the wave
@@ -163,18 +191,23 @@ __global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 
     }
 }
 
-template <int TW, int PG, int CG, int KS, bool UP>
+template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false>
 static hipError_t launch_conv(const ConvArgs& a, int n_img, hipStream_t s) {
     constexpr int TH = PG * (32 / TW);
     const dim3 grid((a.H / TH) * (a.W / TW), (a.Cout / (32 * CG)) * (UP ? 4 : 1), n_img);
-    hipLaunchKernelGGL((conv_kernel<TW, PG, CG, KS, UP>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_kernel<TW, PG, CG, KS, UP, FUSE>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 // conv3x3 / conv1x1 / transpose-conv dispatch on the image size (64/32/16 -> 8x16 pixel tiles, 8 -> 8x8 tiles)
 static hipError_t conv(const float* in0, int C0, const float* in1, int C1, const float* w, const float* b, float* out,
-                       float* pool_out, int HW, int Cout, int ks, bool up, bool relu, int n_img, hipStream_t s) {
-    ConvArgs a{in0, in1, w, b, out, pool_out, HW, HW, C0, C1, Cout, relu ? 1 : 0};
+                       float* pool_out, int HW, int Cout, int ks, bool up, bool relu, int n_img, hipStream_t s,
+                       const float* fuse_w = nullptr, const float* fuse_b = nullptr) {
+    ConvArgs a{in0, in1, w, b, out, pool_out, HW, HW, C0, C1, Cout, relu ? 1 : 0, fuse_w, fuse_b};
+    if (fuse_w != nullptr) {
+        if (HW < 16 || ks != 3 || up || Cout != 32) return hipErrorInvalidValue;
+        return launch_conv<16, 4, 1, 3, false, true>(a, n_img, s);
+    }
     if (HW >= 16) {
         if (up) return launch_conv<16, 4, 1, 1, true>(a, n_img, s);
         if (ks == 3) return launch_conv<16, 4, 1, 3, false>(a, n_img, s);
@@ -202,6 +235,7 @@ hipError_t launch_unet(const UNetWeights& W, const float* x, float* out, float* 
     float* p2 = take(16384);
     float *d3a = take(16384), *d3 = take(16384);
     float* p3 = take(8192);
+    (void)u2;                                // conv_final is fused into the layer that produced u2; the slot stays in the layout
     hipError_t e;
 #define IFD_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
     // encoder pathway (DownConv, unet.py:66-72): conv-relu, conv-relu, pool (not on the last level)
@@ -222,8 +256,9 @@ hipError_t launch_unet(const UNetWeights& W, const float* x, float* out, float* 
     IFD_TRY(conv(u1a, 64, nullptr, 0, W.up_w[1][1], W.up_b[1][1], u1, nullptr, 32, 64, 3, false, true, n_img, s));
     IFD_TRY(conv(u1, 64, nullptr, 0, W.up_t_w[2], W.up_t_b[2], u2up, nullptr, 32, 32, 1, true, false, n_img, s));
     IFD_TRY(conv(u2up, 32, d0, 32, W.up_w[2][0], W.up_b[2][0], u2a, nullptr, 64, 32, 3, false, true, n_img, s));
-    IFD_TRY(conv(u2a, 32, nullptr, 0, W.up_w[2][1], W.up_b[2][1], u2, nullptr, 64, 32, 3, false, true, n_img, s));
-    IFD_TRY(conv(u2, 32, nullptr, 0, W.fin_w, W.fin_b, out, nullptr, 64, 32, 1, false, false, n_img, s));   // conv1x1
+    // last conv-relu with conv_final (conv1x1, unet.py:238) fused into its epilogue
+    IFD_TRY(conv(u2a, 32, nullptr, 0, W.up_w[2][1], W.up_b[2][1], out, nullptr, 64, 32, 3, false, true, n_img, s, W.fin_w,
+                 W.fin_b));
 #undef IFD_TRY
     return hipSuccess;
 }
