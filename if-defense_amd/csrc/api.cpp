@@ -178,7 +178,7 @@ std::vector<float> build_dec_image(const float* w) {
     return img;
 }
 
-bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > MAXK; }
+bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > LARGE_MAXK; }
 
 // Grow the context workspace.  Growing synchronises the device (hipFree), which only happens when a call
 // needs more scratch than any earlier call on this context.
@@ -408,8 +408,8 @@ int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uin
             void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    if (!pc || !keep_mask || B < 1 || K < 2 || K > 2048 || k < 1 || k > 7 || k >= K)
-        return fail(ctx, IFD_ERR_ARG, "ifd_sor: bad argument (2 <= K <= 2048, 1 <= k <= 7)");
+    if (!pc || !keep_mask || B < 1 || K < 2 || K > 4096 || k < 1 || k > 7 || k >= K)
+        return fail(ctx, IFD_ERR_ARG, "ifd_sor: bad argument (2 <= K <= 4096, 1 <= k <= 7)");
     hipError_t e = launch_sor(pc, B, K, k, (double)alpha, keep_mask, value, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_sor launch", e);
 }
@@ -420,8 +420,8 @@ int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, 
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (!pc || !prm || prm->struct_size != (int32_t)sizeof(ifd_prep_params) || !sel || !t_per_cloud || !init_points ||
-        B < 1 || K < 1 || K > 2048 || prm->n_sel < 1 || prm->n_sel > 1024 || prm->n_opt < 1)
-        return fail(ctx, IFD_ERR_ARG, "ifd_prepare: bad argument (K <= 2048, n_sel <= 1024)");
+        B < 1 || K < 1 || K > 4096 || prm->n_sel < 1 || prm->n_sel > 1024 || prm->n_opt < 1)
+        return fail(ctx, IFD_ERR_ARG, "ifd_prepare: bad argument (K <= 4096, n_sel <= 1024)");
     PrepArgs a;
     a.cloud_base = (int)prm->cloud_index_base; a.n_sel = prm->n_sel; a.n_opt = prm->n_opt;
     a.padding_scale = prm->padding_scale; a.init_sigma = prm->init_sigma;
@@ -490,9 +490,9 @@ int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float
                   void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    if (!p || !loss || bad_bk(B, K)) return fail(ctx, IFD_ERR_ARG, "ifd_repulsion: bad argument (6 <= K <= 1024)");
-    hipError_t e = launch_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f,
-                                    static_cast<hipStream_t>(stream));
+    if (!p || !loss || bad_bk(B, K)) return fail(ctx, IFD_ERR_ARG, "ifd_repulsion: bad argument (6 <= K <= 4096)");
+    hipError_t e = K <= MAXK ? launch_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f, static_cast<hipStream_t>(stream))
+                             : launch_large_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_repulsion launch", e);
 }
 
@@ -502,7 +502,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: not a ConvONet context (use ifd_onet_optimize)");
     if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
-        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 1024)");
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 4096)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
@@ -512,12 +512,18 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;
-    hipError_t e = ensure_ws(ctx, knn_list_bytes(B));
+    const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (optimize.hip)
+    hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : knn_list_bytes(B));
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
     e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
+    if (large) {
+        e = launch_large_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
+                                  static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
+    }
     e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, static_cast<uint16_t*>(ctx->ws), ctx->d_counters,
                         static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
@@ -540,8 +546,9 @@ int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    if (!p || B < 1 || K < 1 || K > MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument");
-    hipError_t e = launch_normalize(p, B, K, static_cast<hipStream_t>(stream));
+    if (!p || B < 1 || K < 1 || K > LARGE_MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument (1 <= K <= 4096)");
+    hipError_t e = K <= MAXK ? launch_normalize(p, B, K, static_cast<hipStream_t>(stream))
+                             : launch_large_normalize(p, B, K, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_normalize launch", e);
 }
 
@@ -673,7 +680,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: not an ONet context");
-    if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
+    if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K) || K > MAXK)
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 1024)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))

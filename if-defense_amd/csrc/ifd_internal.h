@@ -55,6 +55,14 @@ hipError_t launch_decode(const float* dec_img, const float* planes, const float*
 hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
                             float h, float eps, hipStream_t s);
 hipError_t launch_normalize(float* p, int B, int K, hipStream_t s);
+// clouds of MAXK < K <= LARGE_MAXK optimised points: two launches per Adam step (optimize.hip, "large" section)
+size_t large_ws_bytes(int B, int K, bool own_moments);
+hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
+                                 const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B, int K,
+                                 const OptArgs& a, hipStream_t s);
+hipError_t launch_large_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
+                                  float h, float eps, hipStream_t s);
+hipError_t launch_large_normalize(float* p, int B, int K, hipStream_t s);
 
 // ---- ONet-Opt (onet.hip) --------------------------------------------------------------------------------
 // offsets (floats) into the canonical ONet weight vector (include/ifd.h order)

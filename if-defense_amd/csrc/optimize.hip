@@ -1163,6 +1163,210 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Clouds of more than MAXK optimised points (--sample_npoint up to LARGE_MAXK = 4096)
+// ---------------------------------------------------------------------------------------------
+// The persistent kernel keeps a cloud's whole optimiser state in one CU's LDS, which ends at 1024 points; the reference
+// has no such limit (opt_defense.py:27).  Larger clouds run the same arithmetic as two launches per Adam step:
+//   large_occupancy_kernel   decoder forward + input-backward of every point (the stand-alone tile, BCE seed) -> G
+//   large_step_kernel        one workgroup per cloud: exact 5-NN by brute-force scan, repulsion terms into the same
+//                            fixed-point accumulators, Adam (moments in global memory), new points
+// The neighbour search is O(K^2) per step here (no certified lists) - a correct path for the rare large request, not a
+// tuned one: ~4x (K = 2048) to ~20x (K = 4096) the per-point cost of the persistent kernel.
+constexpr int LARGE_THREADS = 1024;
+constexpr int LARGE_PPT = LARGE_MAXK / LARGE_THREADS;      // points per thread: 4
+
+__global__ __launch_bounds__(OPT_THREADS, 2) void large_occupancy_kernel(const float* __restrict__ dec_img,
+                                                                          const float* __restrict__ planes,
+                                                                          const float* __restrict__ p, int K,
+                                                                          const int32_t* __restrict__ loss_batch_per_cloud,
+                                                                          int loss_batch, float thr,
+                                                                          f32x4* __restrict__ G, DecConst dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W = smem;
+    const int cloud = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    load_dec_image(W, dec_img);
+    __syncthreads();
+    const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
+    const float* pc = p + (size_t)cloud * K * 3;
+    const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
+    const float inv_lb = 1.0f / (float)lb;
+    const int ntiles = (K + 15) >> 4, nw = (int)(blockDim.x >> 6);
+    for (int tile = blockIdx.y * nw + wave; tile < ntiles; tile += (int)gridDim.y * nw) {
+        const int tp = min(tile * 16 + (lane & 15), K - 1);
+        const float x0 = pc[3 * tp], x1 = pc[3 * tp + 1], x2 = pc[3 * tp + 2];
+        float logit, bce, dx[3] = {0.f, 0.f, 0.f};
+        decoder_tile<MODE_OPT, true, 2>(W, pl, x0, x1, x2, lane, dc, thr, inv_lb, logit, bce, dx);
+        if (lane < 16 && tile * 16 + lane < K) G[(size_t)cloud * K + tp] = f32x4{dx[0], dx[1], dx[2], bce};
+    }
+}
+
+struct LargeLds {
+    f32x4* X;
+    RepAcc F;
+    float* scratch;
+};
+__device__ __forceinline__ LargeLds large_lds(float* smem) {
+    LargeLds l;
+    l.X = reinterpret_cast<f32x4*>(smem);                                             // [LARGE_MAXK]
+    l.F.xy = reinterpret_cast<long long*>(l.X + LARGE_MAXK);                          // [LARGE_MAXK]
+    l.F.z = reinterpret_cast<int*>(l.F.xy + LARGE_MAXK);                              // [LARGE_MAXK]
+    l.scratch = reinterpret_cast<float*>(l.F.z + LARGE_MAXK);                         // [64]
+    return l;
+}
+constexpr size_t LARGE_LDS = (size_t)LARGE_MAXK * (16 + 8 + 4) + 64 * 4;              // 114,944 B
+
+// exact 5-NN + repulsion terms of the points of this thread, two at a time (the persistent kernel's rep_point2)
+__device__ __forceinline__ void large_knn_rep(const LargeLds& l, int K, const RepConst rc, float (&rep_l)[LARGE_PPT],
+                                              int32_t* __restrict__ knn_idx) {
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int r = 0; r < LARGE_PPT; r += 2) {
+        if (r * LARGE_THREADS >= K) break;                                            // block-uniform
+        const int pa = tid + r * LARGE_THREADS, pb = pa + LARGE_THREADS;
+        Top5 ta, tb;
+        knn_scan2(l.X, K, pa, pb, ta, tb);
+        float la, lb;
+        rep_point2(l.X, l.F, K, pa, pb, ta, tb, rc, la, lb);
+        rep_l[r] = pa < K ? la : 0.f;
+        rep_l[r + 1] = pb < K ? lb : 0.f;
+        if (knn_idx != nullptr) {
+            if (pa < K) { int32_t* o = knn_idx + (size_t)pa * 5; o[0] = ta.i0; o[1] = ta.i1; o[2] = ta.i2; o[3] = ta.i3; o[4] = ta.i4; }
+            if (pb < K) { int32_t* o = knn_idx + (size_t)pb * 5; o[0] = tb.i0; o[1] = tb.i1; o[2] = tb.i2; o[3] = tb.i3; o[4] = tb.i4; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __restrict__ p, float* __restrict__ m_io,
+                                                                    float* __restrict__ v_io, const f32x4* __restrict__ G,
+                                                                    int K, const float* __restrict__ adam_tab, int step,
+                                                                    const int32_t* __restrict__ loss_batch_per_cloud,
+                                                                    int loss_batch, float rep_weight, RepConst rc,
+                                                                    float* __restrict__ loss_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LargeLds l = large_lds(smem);
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    float* pc = p + (size_t)cloud * K * 3;
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+        if (pt < K) l.X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
+        l.F.xy[pt] = 0;
+        l.F.z[pt] = 0;
+    }
+    __syncthreads();
+    float rep_l[LARGE_PPT] = {0.f, 0.f, 0.f, 0.f};
+    if (rep_weight > 0.f) large_knn_rep(l, K, rc, rep_l, nullptr);
+    __syncthreads();
+    const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
+    const float rep_scale = rep_weight / ((float)lb * (float)K * 5.f);
+    const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
+    float occ = 0.f, rep = 0.f;
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+        if (pt >= K) continue;
+        const f32x4 go = G[(size_t)cloud * K + pt];
+        const f32x4 x = l.X[pt];
+        const float gocc[3] = {go.x, go.y, go.z};
+        float xs[3] = {x.x, x.y, x.z};
+        int fi[3];
+        unpack_xy(l.F.xy[pt], fi[0], fi[1]);
+        fi[2] = l.F.z[pt];
+        const size_t o = ((size_t)cloud * K + pt) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {                         // the persistent kernel's adam_phase, term by term
+            const float gn = (float)fi[a] * FIX32_INV;
+            const float gr = gn * rep_scale;
+            const float g = gocc[a] + gr;
+            float mr = m_io[o + a], vr = v_io[o + a];
+            mr = mr + (g - mr) * (1.f - 0.9f);
+            vr = vr * 0.999f + (1.f - 0.999f) * g * g;
+            const float denom = sqrtf(vr) / bc2 + 1e-8f;
+            xs[a] = xs[a] - step_size * (mr / denom);
+            m_io[o + a] = mr;
+            v_io[o + a] = vr;
+            pc[3 * pt + a] = xs[a];
+        }
+        occ += go.w;
+        rep += rep_l[r];
+    }
+    if (loss_out != nullptr) {                                // losses at the pre-update points of this (the last) step
+        occ = block_sum(occ, l.scratch);
+        rep = block_sum(rep, l.scratch);
+        if (tid == 0) { loss_out[2 * cloud] = occ; loss_out[2 * cloud + 1] = rep / ((float)K * 5.f); }
+    }
+}
+
+// repulsion_loss(p) for K > MAXK (ifd_repulsion): loss [B], optional gradient and neighbour indices
+__global__ __launch_bounds__(LARGE_THREADS) void large_repulsion_kernel(const float* __restrict__ p, int K,
+                                                                         float* __restrict__ loss, float* __restrict__ grad,
+                                                                         int32_t* __restrict__ knn_idx, RepConst rc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LargeLds l = large_lds(smem);
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const float* pc = p + (size_t)cloud * K * 3;
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+        if (pt < K) l.X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
+        l.F.xy[pt] = 0;
+        l.F.z[pt] = 0;
+    }
+    __syncthreads();
+    float rep_l[LARGE_PPT] = {0.f, 0.f, 0.f, 0.f};
+    large_knn_rep(l, K, rc, rep_l, knn_idx ? knn_idx + (size_t)cloud * K * 5 : nullptr);
+    const float tot = block_sum(rep_l[0] + rep_l[1] + rep_l[2] + rep_l[3], l.scratch);     // (barriers inside: F complete)
+    if (tid == 0) loss[cloud] = tot / ((float)K * 5.f);
+    if (grad != nullptr) {
+        const float sc = 1.f / ((float)K * 5.f);
+#pragma unroll
+        for (int r = 0; r < LARGE_PPT; ++r) {
+            const int pt = tid + r * LARGE_THREADS;
+            if (pt >= K) continue;
+            int fi[3];
+            unpack_xy(l.F.xy[pt], fi[0], fi[1]);
+            fi[2] = l.F.z[pt];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) grad[((size_t)cloud * K + pt) * 3 + a] = (float)fi[a] * FIX32_INV * sc;
+        }
+    }
+}
+
+// normalize_batch_pc (opt_defense.py:76-83) for K > MAXK
+__global__ __launch_bounds__(LARGE_THREADS) void large_normalize_kernel(float* __restrict__ p, int K) {
+    __shared__ float scratch[64];
+    float* pc = p + (size_t)blockIdx.x * K * 3;
+    const int tid = threadIdx.x;
+    float x[LARGE_PPT][3];
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { x[r][a] = pt < K ? pc[3 * pt + a] : 0.f; s[a] += x[r][a]; }
+    }
+    float c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = block_sum(s[a], scratch) / (float)K;
+    float dm = 0.f;
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[r][a] -= c[a];
+        if (pt < K) dm = fmaxf(dm, sqrtf(x[r][0] * x[r][0] + x[r][1] * x[r][1] + x[r][2] * x[r][2]));
+    }
+    const float md = block_max(dm, scratch);
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+        if (pt < K)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pc[3 * pt + a] = x[r][a] / md;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 #ifdef IFD_PROF
@@ -1183,6 +1387,15 @@ hipError_t configure_optimize_kernels() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_occupancy_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_step_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_repulsion_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_LDS);
     return e;
 }
 
@@ -1223,6 +1436,49 @@ hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* gr
                             float radius, float h, float eps, hipStream_t s) {
     RepConst rc = {radius, h, eps};
     hipLaunchKernelGGL(repulsion_kernel, dim3(B), dim3(OPT_THREADS), REP_LDS, s, p, K, loss, grad, knn_idx, rc);
+    return hipGetLastError();
+}
+
+size_t large_ws_bytes(int B, int K, bool own_moments) {
+    return (size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0);
+}
+
+// ws: [B][K] f32x4 occupancy gradients, then (m == nullptr) the two moment arrays, zeroed here
+hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
+                                 const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B, int K,
+                                 const OptArgs& a, hipStream_t s) {
+    f32x4* G = static_cast<f32x4*>(ws);
+    if (m == nullptr) {
+        m = reinterpret_cast<float*>(G + (size_t)B * K);
+        v = m + (size_t)B * K * 3;
+        hipError_t e = hipMemsetAsync(m, 0, (size_t)B * K * 3 * 4 * 2, s);
+        if (e != hipSuccess) return e;
+    }
+    const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
+    // enough decoder workgroups to fill the GPU when there are few clouds: (K / 16) tiles over 8 waves each
+    const int parts = B >= 512 ? 1 : min((K / 16 + 7) / 8, max(1, 512 / B));
+    for (int step = 0; step < a.steps; ++step) {
+        hipLaunchKernelGGL(large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
+                           loss_batch_per_cloud, a.loss_batch, a.threshold, G, a.dc);
+        hipLaunchKernelGGL(large_step_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LDS, s, p, m, v, G, K, adam_tab, step,
+                           loss_batch_per_cloud, a.loss_batch, a.rep_weight, rc,
+                           (step == a.steps - 1) ? loss : nullptr);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.normalize) hipLaunchKernelGGL(large_normalize_kernel, dim3(B), dim3(LARGE_THREADS), 0, s, p, K);
+    return hipGetLastError();
+}
+
+hipError_t launch_large_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
+                                  float h, float eps, hipStream_t s) {
+    RepConst rc = {radius, h, eps};
+    hipLaunchKernelGGL(large_repulsion_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LDS, s, p, K, loss, grad, knn_idx, rc);
+    return hipGetLastError();
+}
+
+hipError_t launch_large_normalize(float* p, int B, int K, hipStream_t s) {
+    hipLaunchKernelGGL(large_normalize_kernel, dim3(B), dim3(LARGE_THREADS), 0, s, p, K);
     return hipGetLastError();
 }
 

@@ -13,7 +13,8 @@
 namespace ifd {
 
 constexpr int PREP_THREADS = 1024;
-constexpr int PREP_MAXK = 2048;          // largest input cloud (points) these kernels accept
+constexpr int PREP_MAXK = 4096;          // largest input cloud (points) these kernels accept
+constexpr int PREP_PPT = PREP_MAXK / PREP_THREADS;   // points per thread: 4
 
 // ---- Philox-4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
@@ -61,10 +62,10 @@ __device__ __forceinline__ float block_minmax_f(float v, bool is_max, float* scr
 __global__ __launch_bounds__(PREP_THREADS) void sor_kernel(const float* __restrict__ pc, int K, int k_nn, double alpha,
                                                             uint8_t* __restrict__ keep, double* __restrict__ value_out) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
-    double* X = dsm;                      // [K][3]
-    double* XX = X + 3 * PREP_MAXK;       // [K]   |x|^2
-    double* VAL = XX + PREP_MAXK;         // [K]
-    double* scratch = VAL + PREP_MAXK;    // [16]
+    double* X = dsm;                      // [K][3]        (the launch sizes the LDS by K: 4 K + 16 doubles)
+    double* XX = X + 3 * K;               // [K]   |x|^2
+    double* scratch = XX + K;             // [16]
+    double val[PREP_PPT];                 // value of point tid + 1024 r (registers: the LDS would not hold a fifth array at 4096)
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = pc + (size_t)b * K * 3;
     for (int i = tid; i < K; i += PREP_THREADS) {
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(PREP_THREADS) void sor_kernel(const float* __restri
     }
     __syncthreads();
     double vsum = 0.0;
-    for (int i = tid; i < K; i += PREP_THREADS) {
+#pragma unroll
+    for (int r = 0; r < PREP_PPT; ++r) {
+        const int i = tid + r * PREP_THREADS;
+        val[r] = 0.0;
+        if (i >= K) continue;
         const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2], xx = XX[i];
         // k_nn + 1 smallest of dist[i][j] = xx_j + (-2 x_i.x_j) + xx_i over ALL j (self included, as the reference);
         // k_nn <= 7
@@ -98,16 +103,20 @@ __global__ __launch_bounds__(PREP_THREADS) void sor_kernel(const float* __restri
 #pragma unroll
         for (int q = 1; q < 8; ++q) v += q <= k_nn ? best[q] : 0.0;
         v /= (double)k_nn;
-        VAL[i] = v;
+        val[r] = v;
         vsum += v;
         if (value_out) value_out[(size_t)b * K + i] = v;
     }
     const double mean = block_sum_d(vsum, scratch) / (double)K;
     double sq = 0.0;
-    for (int i = tid; i < K; i += PREP_THREADS) { const double d = VAL[i] - mean; sq += d * d; }
+#pragma unroll
+    for (int r = 0; r < PREP_PPT; ++r)
+        if (tid + r * PREP_THREADS < K) { const double d = val[r] - mean; sq += d * d; }
     const double var = block_sum_d(sq, scratch) / (double)(K - 1);       // torch.std: unbiased
     const double thr = mean + alpha * sqrt(var);
-    for (int i = tid; i < K; i += PREP_THREADS) keep[(size_t)b * K + i] = VAL[i] <= thr ? 1 : 0;
+#pragma unroll
+    for (int r = 0; r < PREP_PPT; ++r)
+        if (tid + r * PREP_THREADS < K) keep[(size_t)b * K + tid + r * PREP_THREADS] = val[r] <= thr ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -118,10 +127,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
                                                                 int32_t* __restrict__ t_per_cloud, float* __restrict__ init,
                                                                 int32_t* __restrict__ n_kept, float* __restrict__ proc_out) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float* P = fsm;                                                   // [PREP_MAXK][3] kept points, then processed
-    uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * PREP_MAXK);   // [PREP_MAXK] random keys for the subset
-    int* POS = reinterpret_cast<int*>(KEY + PREP_MAXK);               // [PREP_MAXK] compaction prefix
-    float* scratch = reinterpret_cast<float*>(POS + PREP_MAXK);       // [64]
+    float* P = fsm;                                                   // [K][3] kept points, then processed
+    uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * K);           // [K] random keys for the subset
+    int* POS = reinterpret_cast<int*>(KEY + K);                       // [K] compaction prefix
+    float* scratch = reinterpret_cast<float*>(POS + K + (K & 1));     // [64]  (8-byte aligned: holds doubles)
     int* s_n = reinterpret_cast<int*>(scratch + 62);
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t gcloud = (uint32_t)(A.cloud_base + b);
@@ -227,23 +236,27 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
     }
 }
 
-constexpr size_t SOR_LDS = (5 * PREP_MAXK + 16) * sizeof(double);                       // 82,048 B
-constexpr size_t PREP_LDS = 3 * PREP_MAXK * 4 + PREP_MAXK * 4 + PREP_MAXK * 4 + 64 * 4;   // 41,216 B
+// LDS by the cloud size: SOR 32 K + 128 B (131,200 B at K = 4096, 32,896 B at 1024), prepare 20 K + 260 B
+static size_t sor_lds(int K) { return ((size_t)4 * K + 16) * sizeof(double); }
+static size_t prep_lds(int K) { return (size_t)20 * K + 4 * (K & 1) + 64 * 4; }
 
 hipError_t configure_prep_kernels() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SOR_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sor_lds(PREP_MAXK));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)prep_lds(PREP_MAXK));
 }
 
 hipError_t launch_sor(const float* pc, int B, int K, int k_nn, double alpha, uint8_t* keep, double* value, hipStream_t s) {
-    hipLaunchKernelGGL(sor_kernel, dim3(B), dim3(PREP_THREADS), SOR_LDS, s, pc, K, k_nn, alpha, keep, value);
+    hipLaunchKernelGGL(sor_kernel, dim3(B), dim3(PREP_THREADS), sor_lds(K), s, pc, K, k_nn, alpha, keep, value);
     return hipGetLastError();
 }
 
 hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, const PrepArgs& a, const int32_t* sel_idx,
                           const int32_t* init_idx, const float* noise, float* sel, int32_t* t_per_cloud, float* init,
                           int32_t* n_kept, float* proc_out, hipStream_t s) {
-    hipLaunchKernelGGL(prepare_kernel, dim3(B), dim3(PREP_THREADS), PREP_LDS, s, pc, keep, K, a, sel_idx, init_idx, noise,
+    hipLaunchKernelGGL(prepare_kernel, dim3(B), dim3(PREP_THREADS), prep_lds(K), s, pc, keep, K, a, sel_idx, init_idx, noise,
                        sel, t_per_cloud, init, n_kept, proc_out);
     return hipGetLastError();
 }

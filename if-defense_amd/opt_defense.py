@@ -124,8 +124,8 @@ def check_supported(cfg, model="convonet"):
 
 
 # Sizes the kernels hold in LDS (include/ifd.h): more than the reference's Python needs, but finite.
-MAX_SAMPLE_NPOINT = 1024      # optimised points per cloud (MAXK)
-MAX_INPUT_POINTS = 2048       # points per input cloud (SOR / preprocess)
+MAX_SAMPLE_NPOINT = {"convonet": 4096, "onet": 1024}   # optimised points per cloud (ConvONet: > 1024 takes the two-launch-per-step path)
+MAX_INPUT_POINTS = 4096       # points per input cloud (SOR / preprocess)
 MAX_ENCODER_POINTS = 1024     # data.pointcloud_n, the encoder subset
 
 
@@ -136,12 +136,12 @@ def list_inputs(data_root, train):
     return [data_root]
 
 
-def validate_limits(args, cfg, files):
+def validate_limits(args, cfg, files, model="convonet"):
     """Reject what the kernels cannot hold BEFORE the checkpoint is loaded and the process group exists - on every rank,
     with the limit named (the reference accepts any size; here a too-large one would only surface as IFD_ERR_ARG after
     minutes of set-up)."""
-    if not 6 <= args.sample_npoint <= MAX_SAMPLE_NPOINT:
-        raise SystemExit("--sample_npoint %d: this build optimises 6 ... %d points per cloud" % (args.sample_npoint, MAX_SAMPLE_NPOINT))
+    if not 6 <= args.sample_npoint <= MAX_SAMPLE_NPOINT[model]:
+        raise SystemExit("--sample_npoint %d: this build optimises 6 ... %d points per cloud" % (args.sample_npoint, MAX_SAMPLE_NPOINT[model]))
     n_in = int(cfg['data']['pointcloud_n'])
     if not 1 <= n_in <= MAX_ENCODER_POINTS:
         raise SystemExit("data.pointcloud_n %d: the encoder takes at most %d points per cloud" % (n_in, MAX_ENCODER_POINTS))
@@ -169,7 +169,7 @@ def main(argv=None, model="convonet", restorer_factory=None, backend=None, devic
     cfg = load_config(args.config, 'configs/default.yaml', model)
     check_supported(cfg, model)
     files = list_inputs(args.data_root, args.train)
-    validate_limits(args, cfg, files)
+    validate_limits(args, cfg, files, model)
 
     import torch
     from . import DefenseArgs, defend_npz_test_data, defend_npz_train_test_data, defend_point_cloud

@@ -47,7 +47,7 @@ def main(argv=None):
 
     files = list_inputs(args.data_root, args.train)
     args.batch_size, args.iterations = 1, 0                       # (not flags of this CLI; validate_limits looks at them)
-    validate_limits(args, cfg, files)
+    validate_limits(args, cfg, files, "onet")
 
     import torch
     from . import DefenseArgs, OnetRestorer, defend_npz_test_data, remesh_point_cloud, weights, get_save_name

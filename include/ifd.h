@@ -95,7 +95,7 @@ const char* ifd_last_error(const ifd_ctx* ctx);   /* ctx may be NULL: error of t
 
 /* sor_process / SORDefense.outlier_removal (ConvONet/opt_defense.py:86-111, defense/SOR.py:22-49):
  * pc [B,K,3] -> keep_mask [B,K] (1 = kept: value <= mean + alpha * std, float64 like the reference);
- * value (optional) [B,K] float64 = mean of the k nearest squared distances.  2 <= K <= 2048, k <= 7. */
+ * value (optional) [B,K] float64 = mean of the k nearest squared distances.  2 <= K <= 4096, k <= 7. */
 int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uint8_t* keep_mask,
             double* value, void* stream);
 
@@ -114,7 +114,7 @@ typedef struct ifd_prep_params {
  * (np.random.choice without replacement), init_idx [B,n_opt] (torch.randint), noise [B,n_opt,3] ~ N(0,1).
  * Outputs: sel [B,n_sel,3] (rows >= t_per_cloud[b] are zero), t_per_cloud [B] = min(n_kept, n_sel),
  * init_points [B,n_opt,3], n_kept (optional) [B], proc (optional) [B,K,3]: the processed kept points,
- * first n_kept[b] rows valid.  K <= 2048, n_sel <= 1024. */
+ * first n_kept[b] rows valid.  K <= 4096, n_sel <= 1024. */
 int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, int K, const ifd_prep_params* prm,
                 const int32_t* sel_idx, const int32_t* init_idx, const float* noise, float* sel,
                 int32_t* t_per_cloud, float* init_points, int32_t* n_kept, float* proc, void* stream);
@@ -181,7 +181,9 @@ typedef struct ifd_opt_params {
  * pre-update points (what the reference prints at :229-236, before 1/B and weights).
  * loss_batch_per_cloud (optional) [B] int32: overrides prm->loss_batch per cloud, so clouds that belong to
  * different reference batches (the last batch of a file is shorter) can share one launch.
- * 6 <= K <= 1024. */
+ * 6 <= K <= 4096.  Up to 1024 points a cloud runs in the persistent one-launch kernel; 1025 ... 4096 points take two
+ * launches per Adam step (decoder gradient; exact brute-force 5-NN + repulsion + Adam), same arithmetic, and
+ * knn_scan_every_step / the counters below do not apply. */
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
                  const ifd_opt_params* prm, const int32_t* loss_batch_per_cloud,
                  float* m, float* v, float* loss, void* stream);

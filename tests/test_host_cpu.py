@@ -277,14 +277,14 @@ def test_cli_rejects_sizes_and_missing_files_before_loading_anything(tmp_path):
     ok = tmp_path / "ok.npz"
     np.savez(ok, test_pc=np.zeros((2, 64, 3), np.float32), test_label=np.zeros(2))
     big = tmp_path / "big.npz"
-    np.savez(big, test_pc=np.zeros((1, 4096, 3), np.float32), test_label=np.zeros(1))
+    np.savez(big, test_pc=np.zeros((1, 4097, 3), np.float32), test_label=np.zeros(1))
     nolabel = tmp_path / "nolabel.npz"
     np.savez(nolabel, test_pc=np.zeros((1, 64, 3), np.float32))
 
     def boom(cfg, device):                                          # validation must come first: the model is never built
         raise AssertionError("the model was built before the arguments were validated")
 
-    for argv, word in ((["--data_root", str(ok), "--sample_npoint", "2048"], "sample_npoint"),
+    for argv, word in ((["--data_root", str(ok), "--sample_npoint", "4097"], "sample_npoint"),
                        (["--data_root", str(big)], "points per cloud"),
                        (["--data_root", str(nolabel)], "test_label"),
                        (["--data_root", str(tmp_path / "missing.npz")], "not found"),
