@@ -74,8 +74,11 @@ __device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, in
 //       certificate violated -> this wave runs the exact brute-force scan for this step.
 //   Either way every step uses the exact 5-NN set = the five smallest (distance, index) pairs, like the scan.
 // ---------------------------------------------------------------------------------------------
-constexpr int LIST_F = 16;               // "front": every point within rho_f at build time (evaluated every step)
-constexpr int LIST_B = 32;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
+#ifndef IFD_LIST_F
+#define IFD_LIST_F 16
+#endif
+constexpr int LIST_F = IFD_LIST_F;               // "front": every point within rho_f at build time (evaluated every step)
+constexpr int LIST_B = 48 - IFD_LIST_F;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
 constexpr int LIST_M = LIST_F + LIST_B;  // uint16 entries per point; lists live in global memory (L2-resident)
 
 // Per-step diagnostics of the kNN phase: event counts live in LDS (one atomic by lane 0 per event - they are rare or
@@ -103,6 +106,12 @@ enum { PC_BUILD = 0, PC_EVAL, PC_REP, PC_TILES, PC_WAIT, PC_ADAM, PC_T, PC_KNN0,
 #else
 #define PROF_T0()
 #define PROF_ACC(v)
+#endif
+// -DIFD_TRACE only: finer stamps inside the kNN phase (slots 24 ...; the waits they force shift the phase a little)
+#ifdef IFD_TRACE
+#define TRACE_STAMP(slot, wait_asm) do { asm volatile(wait_asm ::: "memory"); if (cn.lane == 0 && cn.pc) cn.pc[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_STAMP(slot, wait_asm)
 #endif
 #define pc_build PC_BUILD
 #define pc_eval PC_EVAL
@@ -648,6 +657,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
         // the certificate must survive one more step: r5 grows <= 2 mv, own and the others' displacement <= mv each
         // (mv = largest move of the step just taken; a larger next move only costs an exact scan, never correctness)
         const float soft_slack = 4.f * mv;
+        TRACE_STAMP(25, "s_waitcnt lgkmcnt(0)");              // flags and displacement maxima read
         PROF_T0();
         const bool need_a = pa < K && (force || ka.pend), need_b = pb < K && (force || kb.pend);
         if (__any(need_a || need_b)) {
@@ -705,7 +715,9 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
             keys6_init(qb);
             u32x4 wa[LIST_M / 8], wb[LIST_M / 8];
             load_list_words(La, Lb, wa, wb);       // front and ring together: one L2 round trip
+            TRACE_STAMP(26, "s_waitcnt vmcnt(0)");            // list words here
             list_keys6_2<0, LIST_F / 8>(X, wa, wb, ia, ib, qa, qb);
+            TRACE_STAMP(27, "s_nop 0");                        // front evaluated
             float r5a = sqrtf(key_d_upper(qa.k4)), r5b = sqrtf(key_d_upper(qb.k4));
             // every point outside a ball of build radius rho is now farther than rho - (spent budget)
             const bool ok1 = (pa >= K || r5a < (ka.rho_f - hs_a) * 0.99999f - 1e-7f) &&
@@ -722,6 +734,9 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
                 soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
                 soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
             }
+            // (Measured in round 2: 91 % of the wave-steps get here with some point that needs the ring, and in 86 % of those
+            // more than 8 of the wave's 128 points do - letting the wave evaluate such points' lists one at a time, one
+            // entry per lane and six wave-wide minima each, only paid below that count and came out 0.8 % slower overall.)
             // A near-tie between the 5th and 6th key (equal above the index bits: ~10 % of the wave-steps have one
             // somewhere among their 128 points) is settled for THAT point by the exact wave-cooperative query below
             // (~2 k cycles) - re-running the whole wave on the exact insertion path cost ~70 k cycles each time.

@@ -960,6 +960,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             const int z = opaque_zero();
             unpark_knnpt(park, z, PARK_KNN, ka);
             unpark_knnpt(park, z, PARK_KNN + 4, kb);
+            TRACE_STAMP(24, "s_waitcnt vmcnt(0)");            // parked state back from scratch
             uint16_t* La = cloud_lists + (size_t)(pa & (MAXK - 1)) * LIST_M;
             uint16_t* Lb = cloud_lists + (size_t)(pb & (MAXK - 1)) * LIST_M;
             knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb,
