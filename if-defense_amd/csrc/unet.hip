@@ -21,6 +21,9 @@ namespace ifd {
 
 constexpr int CK = 16;               // input channels per LDS chunk
 constexpr int CKP = CK + 1;          // padded pixel stride in LDS (floats)
+#ifndef IFD_UNET_PW
+#define IFD_UNET_PW 2                 // 32-pixel sub-tiles per wave of the 3x3 layers at 16^2 ... 64^2 (A/B: -DIFD_UNET_PW=1)
+#endif
 
 struct ConvArgs {
     const float* in0;      // first input  [N][H][W][C0]
@@ -43,10 +46,12 @@ struct ConvArgs {
 // (lane = channel) into the A-operand layout (lane = pixel), 16 more MFMAs per wave, and the intermediate tensor is
 // neither written nor read back (the stand-alone 1x1 kernel was HBM-bound: 1.4 ms at 45 TFLOP/s).  Same MFMA sequence
 // over the 32 channels as the stand-alone kernel -> bit-identical results.
-template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false>
-__global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 96 VGPRs: five blocks (20 waves) per CU
-    constexpr int RW = 32 / TW;                 // rows per wave
-    constexpr int TH = PG * RW;                 // tile height
+// PW: 32-pixel sub-tiles per wave, stacked vertically (1 or 2).  With 2 a wave runs two independent accumulator chains on
+// every B operand (weight) it reads from LDS and a block covers twice the pixels per staged weight slab and per barrier.
+template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false, int PW = 1>
+__global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) {   // PW 1: <= 96 VGPRs, five blocks (20 waves) per CU
+    constexpr int RW = 32 / TW;                 // rows per 32-pixel sub-tile
+    constexpr int TH = PG * PW * RW;            // tile height
     constexpr int HALO = KS / 2;
     constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
     constexpr int TAPS = KS * KS;
@@ -66,12 +71,14 @@ __global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 
     const int n = blockIdx.z;
     const int Cin = a.C0 + a.C1;
 
-    f32x16 acc;
+    f32x16 acc[PW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int pw = 0; pw < PW; ++pw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pw][r] = 0.f;
 
     const int m = lane & 31, kh = lane >> 5;
-    const int py = pg * RW + m / TW, px = m % TW;                      // pixel of this lane inside the tile
+    const int py = pg * PW * RW + m / TW, px = m % TW;                 // pixel of this lane inside the tile (sub-tile 0)
 
     // Global -> register -> LDS staging, one chunk ahead: the loads of chunk c+1 are issued before the MFMAs of chunk c
     // and land in registers under them; after the barrier they are written to LDS.  (Round 1 staged inside the chunk,
@@ -129,73 +136,80 @@ __global__ __launch_bounds__(256, 5) void conv_kernel(ConvArgs a) {       // <= 
             const float* ap = s_in + ((py + dy) * LW + px + dx) * CKP + kh;
             const float* bp = s_w + (tap * CK + kh) * NCO + cg * 32 + m;
 #pragma unroll
-            for (int ks = 0; ks < CK / 2; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks * NCO], acc, 0, 0, 0);
+            for (int ks = 0; ks < CK / 2; ++ks) {
+                const float b = bp[2 * ks * NCO];
+#pragma unroll
+                for (int pw = 0; pw < PW; ++pw)
+                    acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pw * RW * LW * CKP + 2 * ks], b, acc[pw], 0, 0, 0);
+            }
         }
     }
 
     // ---- epilogue: bias, ReLU, NHWC store (lane = output channel), optional fused 2x2 max-pool --------------
     const int co = co0 + cg * 32 + m;
     const float bv = a.bias[co];
-    float v[16];
+    if constexpr (FUSE) __syncthreads();                               // every wave is done with the weight slab
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        v[r] = acc[r] + bv;
-        if (a.relu) v[r] = fmaxf(v[r], 0.f);
-    }
-    if constexpr (FUSE) {
-        static_assert(CG == 1 && !UP && TAPS * CK * NCO >= 128 * 33, "FUSE: one 32-channel group, tile fits the weight slab");
-        __syncthreads();                                               // every wave is done with the weight slab
-        float* T = s_w + wave * 32 * 33;                               // [32 pixels of this wave][33]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + m] = v[r];
-        f32x16 acc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-        const float* fw = a.fuse_w + kh * 32 + m;                      // B[k = channel][n = output channel]
-        float bw[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) bw[ks] = fw[2 * ks * 32];
-        // (wave-private rows of T: no workgroup barrier needed between the writes above and these reads)
-        const float* tp = T + m * 33 + kh;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tp[2 * ks], bw[ks], acc2, 0, 0, 0);
-        const float fb = a.fuse_b[m];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc2[r] + fb;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mm = (r & 3) + 8 * (r >> 2) + 4 * kh;               // pixel index inside the wave
-        const int oy = y0 + pg * RW + mm / TW, ox = x0 + mm % TW;
-        if (UP) {
-            const int uy = 2 * oy + (uptap >> 1), ux = 2 * ox + (uptap & 1);
-            a.out[(((size_t)n * 2 * a.H + uy) * 2 * a.W + ux) * a.Cout + co] = v[r];
-        } else {
-            a.out[(((size_t)n * a.H + oy) * a.W + ox) * a.Cout + co] = v[r];
-        }
-    }
-    if (!UP && a.pool_out != nullptr) {
-        // partners of pixel mm: mm+1 (register r+1) and mm+TW (TW=16: r+8, TW=8: r+4) - all in this lane
-        constexpr int RSTEP = TW == 16 ? 8 : 4;
+    for (int pw = 0; pw < PW; ++pw) {
+        const int yw = y0 + (pg * PW + pw) * RW;                       // first row of this 32-pixel sub-tile
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool top_left = (r & 1) == 0 && ((r / RSTEP) & 1) == 0;
-            if (top_left) {
-                const int mm = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int oy = y0 + pg * RW + mm / TW, ox = x0 + mm % TW;
-                const float pv = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + RSTEP], v[r + RSTEP + 1]));
-                a.pool_out[(((size_t)n * (a.H / 2) + oy / 2) * (a.W / 2) + ox / 2) * a.Cout + co] = pv;
+            v[r] = acc[pw][r] + bv;
+            if (a.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        if constexpr (FUSE) {
+            static_assert(CG == 1 && !UP && TAPS * CK * NCO >= 128 * 33, "FUSE: one 32-channel group, tile fits the weight slab");
+            float* T = s_w + wave * 32 * 33;                           // [32 pixels of this wave][33], wave-private rows
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kh) * 33 + m] = v[r];
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+            const float* fw = a.fuse_w + kh * 32 + m;                  // B[k = channel][n = output channel]
+            float bw[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) bw[ks] = fw[2 * ks * 32];
+            const float* tp = T + m * 33 + kh;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tp[2 * ks], bw[ks], acc2, 0, 0, 0);
+            const float fb = a.fuse_b[m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc2[r] + fb;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = (r & 3) + 8 * (r >> 2) + 4 * kh;           // pixel index inside the sub-tile
+            const int oy = yw + mm / TW, ox = x0 + mm % TW;
+            if (UP) {
+                const int uy = 2 * oy + (uptap >> 1), ux = 2 * ox + (uptap & 1);
+                a.out[(((size_t)n * 2 * a.H + uy) * 2 * a.W + ux) * a.Cout + co] = v[r];
+            } else {
+                a.out[(((size_t)n * a.H + oy) * a.W + ox) * a.Cout + co] = v[r];
+            }
+        }
+        if (!UP && a.pool_out != nullptr) {
+            // partners of pixel mm: mm+1 (register r+1) and mm+TW (TW=16: r+8, TW=8: r+4) - all in this lane
+            constexpr int RSTEP = TW == 16 ? 8 : 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool top_left = (r & 1) == 0 && ((r / RSTEP) & 1) == 0;
+                if (top_left) {
+                    const int mm = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int oy = yw + mm / TW, ox = x0 + mm % TW;
+                    const float pv = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + RSTEP], v[r + RSTEP + 1]));
+                    a.pool_out[(((size_t)n * (a.H / 2) + oy / 2) * (a.W / 2) + ox / 2) * a.Cout + co] = pv;
+                }
             }
         }
     }
 }
 
-template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false>
+template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false, int PW = 1>
 static hipError_t launch_conv(const ConvArgs& a, int n_img, hipStream_t s) {
-    constexpr int TH = PG * (32 / TW);
+    constexpr int TH = PG * PW * (32 / TW);
     const dim3 grid((a.H / TH) * (a.W / TW), (a.Cout / (32 * CG)) * (UP ? 4 : 1), n_img);
-    hipLaunchKernelGGL((conv_kernel<TW, PG, CG, KS, UP, FUSE>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_kernel<TW, PG, CG, KS, UP, FUSE, PW>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -206,11 +220,11 @@ static hipError_t conv(const float* in0, int C0, const float* in1, int C1, const
     ConvArgs a{in0, in1, w, b, out, pool_out, HW, HW, C0, C1, Cout, relu ? 1 : 0, fuse_w, fuse_b};
     if (fuse_w != nullptr) {
         if (HW < 16 || ks != 3 || up || Cout != 32) return hipErrorInvalidValue;
-        return launch_conv<16, 4, 1, 3, false, true>(a, n_img, s);
+        return launch_conv<16, 4, 1, 3, false, true, IFD_UNET_PW>(a, n_img, s);
     }
     if (HW >= 16) {
         if (up) return launch_conv<16, 4, 1, 1, true>(a, n_img, s);
-        if (ks == 3) return launch_conv<16, 4, 1, 3, false>(a, n_img, s);
+        if (ks == 3) return launch_conv<16, 4, 1, 3, false, false, IFD_UNET_PW>(a, n_img, s);
         return launch_conv<16, 4, 1, 1, false>(a, n_img, s);
     }
     if (up) return launch_conv<8, 2, 2, 1, true>(a, n_img, s);
