@@ -40,7 +40,8 @@ struct ConvArgs {
 
 // TW: tile width in pixels (16 or 8); a wave covers 32/TW rows x TW columns.  PG x CG = 4 waves:
 // PG pixel groups (stacked vertically) x CG groups of 32 output channels.  KS: 3 (pad 1) or 1.
-// UP: ConvTranspose2d(k=2,s=2): blockIdx.y additionally enumerates the 4 (dy,dx) taps.
+// UP: ConvTranspose2d(k=2,s=2): the block computes all 4 (dy,dx) output taps of its input pixels - four accumulators per
+// wave on one A operand (the input pixel), the input tile read once (HBM-bound layers: it was read once per tap).
 // FUSE (Cout = 32, CG = 1): a following conv1x1 (32 -> 32, bias, no ReLU: conv_final, unet.py:238) is applied to the
 // block's activated tile before it leaves the CU - the tile goes through LDS once to turn the accumulator layout
 // (lane = channel) into the A-operand layout (lane = pixel), 16 more MFMAs per wave, and the intermediate tensor is
@@ -49,15 +50,18 @@ struct ConvArgs {
 // PW: 32-pixel sub-tiles per wave, stacked vertically (1 or 2).  With 2 a wave runs two independent accumulator chains on
 // every B operand (weight) it reads from LDS and a block covers twice the pixels per staged weight slab and per barrier.
 template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false, int PW = 1>
-__global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) {   // PW 1: <= 96 VGPRs, five blocks (20 waves) per CU
+__global__ __launch_bounds__(256, (PW == 1 && !UP) ? 5 : 3) void conv_kernel(ConvArgs a) {   // PW 1: <= 96 VGPRs, five blocks (20 waves) per CU
     constexpr int RW = 32 / TW;                 // rows per 32-pixel sub-tile
     constexpr int TH = PG * PW * RW;            // tile height
     constexpr int HALO = KS / 2;
     constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
     constexpr int TAPS = KS * KS;
+    constexpr int WT = UP ? 4 : TAPS;           // weight taps staged per chunk
+    constexpr int NACC = UP ? 4 : PW;           // accumulators per wave
+    static_assert(!UP || (KS == 1 && PW == 1), "transpose convolution: 1x1 input footprint, one sub-tile");
     constexpr int NCO = 32 * CG;                // output channels per block
     __shared__ __attribute__((aligned(16))) float s_in[LH * LW * CKP];
-    __shared__ __attribute__((aligned(16))) float s_w[TAPS * CK * NCO];
+    __shared__ __attribute__((aligned(16))) float s_w[WT * CK * NCO];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pg = wave % PG, cg = wave / PG;
@@ -65,15 +69,14 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
     const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
     const int co_blocks = a.Cout / NCO;
-    const int cob = UP ? (int)blockIdx.y % co_blocks : (int)blockIdx.y;
-    const int uptap = UP ? (int)blockIdx.y / co_blocks : 0;          // dy*2 + dx
+    const int cob = (int)blockIdx.y;
     const int co0 = cob * NCO;
     const int n = blockIdx.z;
     const int Cin = a.C0 + a.C1;
 
-    f32x16 acc[PW];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int pw = 0; pw < PW; ++pw)
+    for (int pw = 0; pw < NACC; ++pw)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pw][r] = 0.f;
 
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
     // (Walking several tiles per block with the look-ahead running across the tile boundary was measured too: the
     // longer live ranges cost registers / occupancy, 82.5 ms against 74.0 ms for the whole U-Net.)
     constexpr int IN_N = LH * LW * (CK / 4), IN_IT = (IN_N + 255) / 256;      // f32x4 loads of the pixel tile per thread
-    constexpr int W_N = TAPS * CK * (NCO / 4), W_IT = (W_N + 255) / 256;      // ... of the weight slab
+    constexpr int W_N = WT * CK * (NCO / 4), W_IT = (W_N + 255) / 256;        // ... of the weight slab
     f32x4 rin[IN_IT], rw[W_IT];
     auto fetch = [&](int c0) {
         const float* src = c0 < a.C0 ? a.in0 : a.in1;
@@ -107,9 +110,8 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
             const int i = tid + it * 256;
             const int q4 = i % (NCO / 4), row = i / (NCO / 4);         // row = tap * CK + k
             const int tap = row / CK, k = row % CK;
-            const int gtap = UP ? uptap : tap;
             if (W_N % 256 == 0 || i < W_N)
-                rw[it] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)gtap * Cin + c0 + k) * a.Cout + co0 + 4 * q4);
+                rw[it] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * Cin + c0 + k) * a.Cout + co0 + 4 * q4);
         }
     };
     fetch(0);
@@ -130,17 +132,29 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
         }
         __syncthreads();
         if (c0 + CK < Cin) fetch(c0 + CK);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = tap / KS, dx = tap % KS;
-            const float* ap = s_in + ((py + dy) * LW + px + dx) * CKP + kh;
-            const float* bp = s_w + (tap * CK + kh) * NCO + cg * 32 + m;
+        if constexpr (UP) {
+            const float* ap = s_in + (py * LW + px) * CKP + kh;
+            const float* bp = s_w + kh * NCO + cg * 32 + m;
 #pragma unroll
             for (int ks = 0; ks < CK / 2; ++ks) {
-                const float b = bp[2 * ks * NCO];
+                const float av = ap[2 * ks];
 #pragma unroll
-                for (int pw = 0; pw < PW; ++pw)
-                    acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pw * RW * LW * CKP + 2 * ks], b, acc[pw], 0, 0, 0);
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[(t * CK + 2 * ks) * NCO], acc[t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int dy = tap / KS, dx = tap % KS;
+                const float* ap = s_in + ((py + dy) * LW + px + dx) * CKP + kh;
+                const float* bp = s_w + (tap * CK + kh) * NCO + cg * 32 + m;
+#pragma unroll
+                for (int ks = 0; ks < CK / 2; ++ks) {
+                    const float b = bp[2 * ks * NCO];
+#pragma unroll
+                    for (int pw = 0; pw < PW; ++pw)
+                        acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pw * RW * LW * CKP + 2 * ks], b, acc[pw], 0, 0, 0);
+                }
             }
         }
     }
@@ -150,8 +164,8 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
     const float bv = a.bias[co];
     if constexpr (FUSE) __syncthreads();                               // every wave is done with the weight slab
 #pragma unroll
-    for (int pw = 0; pw < PW; ++pw) {
-        const int yw = y0 + (pg * PW + pw) * RW;                       // first row of this 32-pixel sub-tile
+    for (int pw = 0; pw < NACC; ++pw) {                                // sub-tile (UP: output tap dy * 2 + dx) of this wave
+        const int yw = y0 + (UP ? pg : pg * PW + pw) * RW;             // first row of this 32-pixel sub-tile
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
             const int mm = (r & 3) + 8 * (r >> 2) + 4 * kh;           // pixel index inside the sub-tile
             const int oy = yw + mm / TW, ox = x0 + mm % TW;
             if (UP) {
-                const int uy = 2 * oy + (uptap >> 1), ux = 2 * ox + (uptap & 1);
+                const int uy = 2 * oy + (pw >> 1), ux = 2 * ox + (pw & 1);
                 a.out[(((size_t)n * 2 * a.H + uy) * 2 * a.W + ux) * a.Cout + co] = v[r];
             } else {
                 a.out[(((size_t)n * a.H + oy) * a.W + ox) * a.Cout + co] = v[r];
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(256, PW == 1 ? 5 : 3) void conv_kernel(ConvArgs a) 
 template <int TW, int PG, int CG, int KS, bool UP, bool FUSE = false, int PW = 1>
 static hipError_t launch_conv(const ConvArgs& a, int n_img, hipStream_t s) {
     constexpr int TH = PG * PW * (32 / TW);
-    const dim3 grid((a.H / TH) * (a.W / TW), (a.Cout / (32 * CG)) * (UP ? 4 : 1), n_img);
+    const dim3 grid((a.H / TH) * (a.W / TW), a.Cout / (32 * CG), n_img);
     hipLaunchKernelGGL((conv_kernel<TW, PG, CG, KS, UP, FUSE, PW>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
