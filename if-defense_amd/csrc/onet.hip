@@ -317,8 +317,7 @@ __device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) part = fmaf(w[r], u[4 * t + r], part);
     }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
+    part = add_lane_xor32(add_lane_xor16(part));
     logit = part + lds[OL_WOUT + ONET_H];
     float dl;
     if (MODE == OMODE_OPT) {
@@ -393,9 +392,9 @@ __device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* 
             const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_FCP + (16 * t + 4 * q + r) * 4);
             g0 = fmaf(w.x, x[t][r], g0); g1 = fmaf(w.y, x[t][r], g1); g2 = fmaf(w.z, x[t][r], g2);
         }
-    g0 += __shfl_xor(g0, 16); g0 += __shfl_xor(g0, 32);
-    g1 += __shfl_xor(g1, 16); g1 += __shfl_xor(g1, 32);
-    g2 += __shfl_xor(g2, 16); g2 += __shfl_xor(g2, 32);
+    g0 = add_lane_xor32(add_lane_xor16(g0));
+    g1 = add_lane_xor32(add_lane_xor16(g1));
+    g2 = add_lane_xor32(add_lane_xor16(g2));
     dx[0] = g0; dx[1] = g1; dx[2] = g2;
 }
 

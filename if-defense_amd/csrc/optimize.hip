@@ -244,8 +244,7 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
     float part = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) part = fmaf(wout[r], fmaxf(nf[r], 0.f), part);
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
+    part = add_lane_xor32(add_lane_xor16(part));
     const float logit = part + W[DEC_OFF_BOUT];
     logit_out = logit;
     bce_out = 0.f;
@@ -336,8 +335,7 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float v = g[a];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
+        v = add_lane_xor32(add_lane_xor16(v));
         dx[a] = v;
     }
 }
@@ -701,8 +699,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         float part = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) part = fmaf(wout[r], rn[r], part);
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
+        part = add_lane_xor32(add_lane_xor16(part));
         const float logit = part + W[DEC_OFF_BOUT];
         float dl;
         if (MODE == MODE_OPT) {
@@ -828,10 +825,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            float v = g[t][a];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            dx[t][a] = v;
+            dx[t][a] = add_lane_xor32(add_lane_xor16(g[t][a]));
         }
     asm volatile("s_setprio 0");
 }
