@@ -277,13 +277,21 @@ __device__ __forceinline__ void knn_build_one(const float (&cx)[16], const float
         hb |= ((in_b && !in_f) ? 1u : 0u) << k;
     }
     const int cf = __popc(hf), cb = __popc(hb);
-    int pf = cf, pb = cb;                                          // wave-inclusive prefix sums
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int tf_ = __shfl_up(pf, o), tb_ = __shfl_up(pb, o);
-        if (lane >= o) { pf += tf_; pb += tb_; }
-    }
-    const int nf = __shfl(pf, 63), nb = __shfl(pb, 63);
+    // wave-inclusive prefix sums of both counts at once (cf | cb << 16; the totals are <= 1024): shifted adds inside the
+    // rows of 16 through DPP (zero fill), the three row totals through readlane - no LDS crossbar (__shfl_up is a
+    // ds_bpermute: the former version was a chain of six dependent LDS round trips per target)
+    int pfb = cf | (cb << 16);
+    pfb += __builtin_amdgcn_update_dpp(0, pfb, 0x111, 0xf, 0xf, true);     // row_shr:1
+    pfb += __builtin_amdgcn_update_dpp(0, pfb, 0x112, 0xf, 0xf, true);     // row_shr:2
+    pfb += __builtin_amdgcn_update_dpp(0, pfb, 0x114, 0xf, 0xf, true);     // row_shr:4
+    pfb += __builtin_amdgcn_update_dpp(0, pfb, 0x118, 0xf, 0xf, true);     // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(pfb, 15), r1 = __builtin_amdgcn_readlane(pfb, 31);
+    const int r2 = __builtin_amdgcn_readlane(pfb, 47), r3 = __builtin_amdgcn_readlane(pfb, 63);
+    const int row = lane >> 4;
+    pfb += (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+    const int tot = r0 + r1 + r2 + r3;
+    const int pf = pfb & 0xffff, pb = pfb >> 16;
+    const int nf = tot & 0xffff, nb = tot >> 16;
     int at_f = pf - cf, at_b = pb - cb;
     while (hf != 0u) {
         const int k = __builtin_ctz(hf);

@@ -970,7 +970,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         for (;;) {
             int tile = 0;
             if (lane == 0) tile = atomicAdd(tile_ctr, 1);
-            tile = __shfl(tile, 0);
+            tile = __builtin_amdgcn_readfirstlane(tile);            // (not __shfl: that is an LDS crossbar round trip)
             if (tile >= ntiles) break;
             const int ia = tile * 32 + (lane & 15), ib = ia + 16;    // two 16-point sub-tiles, software-pipelined
             const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
