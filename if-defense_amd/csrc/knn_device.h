@@ -805,19 +805,17 @@ struct AdamState {
 // (adam_table in api.cpp).  Also reduces this wave's displacement / step-length maxima for the neighbour-list
 // certificates of the next step.
 __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* __restrict__ G, const RepAcc F,
-                                           int K, int pa, int pb, int wave, int lane, int step, float step_size,
-                                           float bc2, float rep_scale, AdamState& st, const KnnPt& ka, const KnnPt& kb,
-                                           const KnnShared& sh) {
-    float* const dmaxbuf = sh.dmaxbuf;
-    float* const movebuf = sh.movebuf;
+                                           int K, int pa, int pb, float step_size, float bc2, float rep_scale,
+                                           AdamState& st, float (&xnew)[2][3], float& mv2_out) {
     float (&mm)[6] = st.mm;
     float (&vv)[6] = st.vv;
     // ---- Adam (torch/optim/adam.py _single_tensor_adam: lerp form, eps added after the bias-
     //      corrected sqrt) ---------------------------------------------------------------------
-    float dmax2 = 0.f, mv2 = 0.f;
+    float mv2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int pt = q ? pb : pa;
+        xnew[q][0] = xnew[q][1] = xnew[q][2] = 0.f;
         if (pt < K) {
             const f32x4 go = G[pt];
             const f32x4 x = X[pt];
@@ -844,20 +842,38 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
                 const float upd = step_size * (mr / denom);
                 xs[a] = xs[a] - upd;
                 msq = fmaf(upd, upd, msq);
+                xnew[q][a] = xs[a];
             }
-            const f32x4 x0 = q ? kb.x0 : ka.x0;
-            const float dsq = (xs[0] - x0.x) * (xs[0] - x0.x) + (xs[1] - x0.y) * (xs[1] - x0.y) +
-                              (xs[2] - x0.z) * (xs[2] - x0.z);
-            dmax2 = fmaxf(dmax2, sqrtf(dsq) + (q ? kb.dbase : ka.dbase));
             mv2 = fmaxf(mv2, msq);
             X[pt] = f32x4{xs[0], xs[1], xs[2], 1.f};     // .w = 1: fc_p's bias input on the matrix pipe (optimize.hip)
+        }
+    }
+    mv2_out = mv2;
+}
+
+// Second half of the Adam phase: this wave's displacement / step-length maxima for the neighbour-list certificates of
+// the next step.  It is the only part that needs the parked per-point state (x0, dbase: a scratch round trip issued just
+// before the mid-step barrier), so it runs LAST - after the update, the sampling coordinates and the moments - and the
+// round trip of the wave that reached the barrier last hides under that work instead of stalling it.
+__device__ __forceinline__ void adam_displacement(int K, int pa, int pb, int wave, int lane, int step,
+                                                  const float (&xnew)[2][3], float mv2, const KnnPt& ka, const KnnPt& kb,
+                                                  const KnnShared& sh) {
+    float dmax2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pt = q ? pb : pa;
+        if (pt < K) {
+            const f32x4 x0 = q ? kb.x0 : ka.x0;
+            const float dsq = (xnew[q][0] - x0.x) * (xnew[q][0] - x0.x) + (xnew[q][1] - x0.y) * (xnew[q][1] - x0.y) +
+                              (xnew[q][2] - x0.z) * (xnew[q][2] - x0.z);
+            dmax2 = fmaxf(dmax2, sqrtf(dsq) + (q ? kb.dbase : ka.dbase));
         }
     }
     dmax2 = wave_max(dmax2);
     mv2 = wave_max(mv2);
     if (lane == 0) {
-        dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = dmax2 * 1.00001f + 1e-7f;
-        movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
+        sh.dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = dmax2 * 1.00001f + 1e-7f;
+        sh.movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
     }
 }
 

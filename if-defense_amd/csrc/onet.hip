@@ -572,8 +572,9 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
         }
-        adam_phase(X, G, F, K, pa, pb, wave, lane, step, adam_tab[2 * step], adam_tab[2 * step + 1], rep_scale, ast, ka, kb,
-                   ksh);
+        float xnew[2][3], mv2;
+        adam_phase(X, G, F, K, pa, pb, adam_tab[2 * step], adam_tab[2 * step + 1], rep_scale, ast, xnew, mv2);
+        adam_displacement(K, pa, pb, wave, lane, step, xnew, mv2, ka, kb, ksh);
         if (tid == 0) rebuild_flag[step & 1] = 0;
         __syncthreads();
     }

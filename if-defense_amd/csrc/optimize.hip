@@ -1013,13 +1013,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
             }
         }
-        adam_phase(X, G, F, K, pa, pb, wave, lane, step, step_size, bc2, rep_scale, ast, ka, kb, ksh);
+        float xnew[2][3], mv2;
+        adam_phase(X, G, F, K, pa, pb, step_size, bc2, rep_scale, ast, xnew, mv2);
+        TRACE_STAMP(28, "s_waitcnt lgkmcnt(0)");              // Adam update done, X written
 #pragma unroll
         for (int q = 0; q < 2; ++q) {        // sampling coordinates of the moved points, for the next step's decoder tiles
             const int pt = q ? pb : pa;
-            if (pt < K) { const f32x4 x = X[pt]; PIX[pt] = pix_encode(x.x, x.y, x.z, dc); }
+            if (pt < K) PIX[pt] = pix_encode(xnew[q][0], xnew[q][1], xnew[q][2], dc);
         }
+        TRACE_STAMP(29, "s_waitcnt lgkmcnt(0)");              // PIX written
         if (owner) store_adam(MV, tid_s, ast);
+        adam_displacement(K, pa, pb, wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
         if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
         __syncthreads();
         PROF_ACC(pc_adam);

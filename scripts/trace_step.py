@@ -24,6 +24,6 @@ for wi, w in enumerate(tr):
     tiles = [rel(v) for v in w[8:20] if v]
     print("%d   %6.1f %6.1f %6.1f %6.1f | %s | %6.1f %6.1f %6.1f" % (wi, rel(w[7]), rel(w[0]), rel(w[1]), rel(w[2]),
           " ".join("%6.1f" % t for t in tiles), rel(w[3]), rel(w[4]), rel(w[5])))
-print("inside the kNN phase (k cycles): unparked, flags read, list words here, front evaluated")
+print("inside the kNN phase (k cycles): unparked, flags read, list words here, front evaluated | after the mid-step barrier: Adam done, PIX written")
 for wi, w in enumerate(tr):
-    print("%d   %s" % (wi, " ".join("%6.1f" % ((v - t0) / 1e3) if v else "   nan" for v in w[24:28])))
+    print("%d   %s" % (wi, " ".join("%6.1f" % ((v - t0) / 1e3) if v else "   nan" for v in w[24:30])))
