@@ -385,6 +385,40 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
     }
 }
 
+// (distance, index)-lexicographic minimum over the wave, in every lane: DPP inside the rows of 16 (xor 1, xor 2, the two
+// mirrors), then the row / half swaps of gfx950 - twelve vector instructions instead of twelve ds_bpermute round trips
+// (__shfl_xor) per call; knn_resolve_failures calls it five times per target and the whole workgroup waits for the
+// wave that runs it.
+__device__ __forceinline__ void lexmin_pair(float& bd, int& bj, float od, int oj) {
+    const bool take = od < bd || (od == bd && oj < bj);
+    bd = take ? od : bd;
+    bj = take ? oj : bj;
+}
+template <int CTRL>
+__device__ __forceinline__ void lexmin_dpp(float& bd, int& bj) {
+    const float od = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(bd), CTRL, 0xf, 0xf, false));
+    const int oj = __builtin_amdgcn_update_dpp(0, bj, CTRL, 0xf, 0xf, false);
+    lexmin_pair(bd, bj, od, oj);
+}
+__device__ __forceinline__ void lexmin_wave(float& bd, int& bj) {
+    lexmin_dpp<0xB1>(bd, bj);        // quad_perm [1,0,3,2]
+    lexmin_dpp<0x4E>(bd, bj);        // quad_perm [2,3,0,1]
+    lexmin_dpp<0x141>(bd, bj);       // row_half_mirror
+    lexmin_dpp<0x140>(bd, bj);       // row_mirror
+    {
+        const u32x2_t d = __builtin_amdgcn_permlane16_swap(__float_as_uint(bd), __float_as_uint(bd), false, false);
+        const u32x2_t j = __builtin_amdgcn_permlane16_swap((unsigned int)bj, (unsigned int)bj, false, false);
+        bd = __uint_as_float(d.x); bj = (int)j.x;
+        lexmin_pair(bd, bj, __uint_as_float(d.y), (int)j.y);
+    }
+    {
+        const u32x2_t d = __builtin_amdgcn_permlane32_swap(__float_as_uint(bd), __float_as_uint(bd), false, false);
+        const u32x2_t j = __builtin_amdgcn_permlane32_swap((unsigned int)bj, (unsigned int)bj, false, false);
+        bd = __uint_as_float(d.x); bj = (int)j.x;
+        lexmin_pair(bd, bj, __uint_as_float(d.y), (int)j.y);
+    }
+}
+
 // Exact 5-NN of a FEW points of this wave whose certificate failed (crowded balls, late failures): the wave's
 // lanes hold the K candidates (16 each), per target five rounds of a (distance, index)-lexicographic minimum -
 // ~500 instructions per target instead of a ~20 k-instruction scan by every lane of the wave.  Falls back to that
@@ -431,14 +465,7 @@ __device__ __forceinline__ void knn_resolve_failures(const f32x4* __restrict__ X
                 for (int k = 1; k < 16; ++k)
                     if (d[k] < bd) { bd = d[k]; bk = k; }            // ascending k = ascending index: ties keep the smaller
                 int bj = lane + 64 * bk;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float od = __shfl_xor(bd, o);
-                    const int oj = __shfl_xor(bj, o);
-                    const bool take = od < bd || (od == bd && oj < bj);
-                    bd = take ? od : bd;
-                    bj = take ? oj : bj;
-                }
+                lexmin_wave(bd, bj);
                 rd[r] = bd;
                 rj[r] = bj;
                 if ((bj & 63) == lane) {
