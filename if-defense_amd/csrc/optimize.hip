@@ -636,6 +636,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 
     // ---- forward MLP, software pipelined ---------------------------------------------------------------------
     Mask8 mask_a[2][NBLK], mask_h[2][NBLK];
+    f32x8 wout;
+    float bout = 0.f;
     int c31 = 31;                                  // shift count of the sign-byte extraction (an SDWA operand must be a register)
     asm volatile("" : "+v"(c31));
 #pragma unroll
@@ -676,19 +678,19 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             A = load_wfrag<false>(Wl + 3 * W_LAYER, lo);
         } else {
             A = load_wfrag<true>(Wl + 2 * W_LAYER, lo);
+            // fc_out's weights and bias ride in with the last region's LDS reads: read after it they would be an LDS round
+            // trip at the head of the forward -> backward chain (logit, sigmoid, seed), where this wave has no MFMA to issue
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + lo.q4);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
+            bout = W[DEC_OFF_BOUT];
         }
         Acc2 o1 = acc_add(B1, a1);
         mfma16(A1, rh1, o1);
         net[0] = o0;
         net[1] = o1;
         region_end<0, 1>();
-    }
-    f32x8 wout;
-    {
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + lo.q4);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
     }
     f32x8 dn[2];
 #pragma unroll
@@ -700,12 +702,12 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #pragma unroll
         for (int r = 0; r < 8; ++r) part = fmaf(wout[r], rn[r], part);
         part = add_lane_xor32(add_lane_xor16(part));
-        const float logit = part + W[DEC_OFF_BOUT];
+        const float logit = part + bout;
         float dl;
         if (MODE == MODE_OPT) {
             // BCE-with-logits against the threshold (opt_defense.py:213-216): d/dlogit = (sigmoid - thr) / B.  The
             // loss value itself is only reported for the last step.
-            const float e = expf(-fabsf(logit));
+            const float e = expf(-fabsf(logit));       // (v_exp_f32 directly: 379.2 against 380.0 k cycles per step - not taken)
             const float rc = __builtin_amdgcn_rcpf(1.f + e);
             const float sig = logit >= 0.f ? rc : e * rc;
             dl = (sig - thr) * inv_lb;
