@@ -74,11 +74,18 @@ __device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, in
 //       certificate violated -> this wave runs the exact brute-force scan for this step.
 //   Either way every step uses the exact 5-NN set = the five smallest (distance, index) pairs, like the scan.
 // ---------------------------------------------------------------------------------------------
+// Sizes re-tuned in round 2 on the bench workload (scripts/ab_bench.sh; kernel launch of 2468 clouds): front / total
+// 16 / 48: 867 ms, 24 / 48: 865, 32 / 48: 864, 40 / 48: 866, 24 / 40: 881, 32 / 56: 857, 16 / 64: 896, 24 / 64: 855, 32 / 64: 852,
+// 40 / 64: 853, 48 / 64: 855 - longer lists mean fewer whole-cloud rebuilds (~140 k cycles per wave each) for more entries
+// evaluated per step, and the evaluation became the cheaper side once it ran on key networks.
 #ifndef IFD_LIST_F
-#define IFD_LIST_F 16
+#define IFD_LIST_F 32
 #endif
 constexpr int LIST_F = IFD_LIST_F;               // "front": every point within rho_f at build time (evaluated every step)
-constexpr int LIST_B = 48 - IFD_LIST_F;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
+#ifndef IFD_LIST_M
+#define IFD_LIST_M 64          // <= 64: knn_build_one fills a list's unused slots one per lane
+#endif
+constexpr int LIST_B = IFD_LIST_M - IFD_LIST_F;               // "back" : the ring rho_f <= d < rho_b (evaluated only when the front fails)
 constexpr int LIST_M = LIST_F + LIST_B;  // uint16 entries per point; lists live in global memory (L2-resident)
 
 // Per-step diagnostics of the kNN phase: event counts live in LDS (one atomic by lane 0 per event - they are rare or
@@ -368,8 +375,11 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
                 kp.rho_b = sqrtf(tb);
                 // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly when sparse
                 if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb / d4; }
-                if (nf < LIST_F / 2) kp.al_f *= 1.15f;
-                if (nf + nb < LIST_M / 2) kp.al_b *= 1.15f;
+#ifndef IFD_FILL_Q
+#define IFD_FILL_Q 2          // grow a radius while its list is less than IFD_FILL_Q / 4 full
+#endif
+                if (4 * nf < IFD_FILL_Q * LIST_F) kp.al_f *= 1.15f;
+                if (4 * (nf + nb) < IFD_FILL_Q * LIST_M) kp.al_b *= 1.15f;
                 kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
                 kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
                 kp.al_f = fminf(kp.al_f, kp.al_b);
