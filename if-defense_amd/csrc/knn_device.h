@@ -620,10 +620,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// max over the wave in every lane: rotations inside the rows of 16 (DPP), then the row and half swaps - no LDS crossbar
+// (__shfl_xor compiles to ds_bpermute: six dependent LDS round trips; the Adam phase does this twice per step, at the end
+// of the step's critical path: -0.45 % of the kernel on the bench workload)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128, 0xf, 0xf, false)));   // row_ror:8
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x124, 0xf, 0xf, false)));   // row_ror:4
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x122, 0xf, 0xf, false)));   // row_ror:2
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x121, 0xf, 0xf, false)));   // row_ror:1
+    const u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a.x), __uint_as_float(a.y));
+    const u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b.x), __uint_as_float(b.y));
 }
 // deterministic block reductions; `scratch` holds >= NWAVES floats
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
@@ -701,7 +709,10 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
         }
         // the certificate must survive one more step: r5 grows <= 2 mv, own and the others' displacement <= mv each
         // (mv = largest move of the step just taken; a larger next move only costs an exact scan, never correctness)
-        const float soft_slack = 4.f * mv;
+#ifndef IFD_SOFT_SLACK
+#define IFD_SOFT_SLACK 4.f
+#endif
+        const float soft_slack = IFD_SOFT_SLACK * mv;
         TRACE_STAMP(25, "s_waitcnt lgkmcnt(0)");              // flags and displacement maxima read
         PROF_T0();
         const bool need_a = pa < K && (force || ka.pend), need_b = pb < K && (force || kb.pend);

@@ -707,7 +707,11 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         if (MODE == MODE_OPT) {
             // BCE-with-logits against the threshold (opt_defense.py:213-216): d/dlogit = (sigmoid - thr) / B.  The
             // loss value itself is only reported for the last step.
+#ifdef IFD_FAST_SIGMOID_EXP
+            const float e = __expf(-fabsf(logit));
+#else
             const float e = expf(-fabsf(logit));       // (v_exp_f32 directly: 379.2 against 380.0 k cycles per step - not taken)
+#endif
             const float rc = __builtin_amdgcn_rcpf(1.f + e);
             const float sig = logit >= 0.f ? rc : e * rc;
             dl = (sig - thr) * inv_lb;
