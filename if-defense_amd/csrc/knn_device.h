@@ -576,12 +576,27 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const Re
             const float ex = xj.x - xi.x, ey = xj.y - xi.y, ez = xj.z - xi.z;
             const float d2raw = ex * ex + ey * ey + ez * ez;
             const float d2 = fmaxf(d2raw, rc.eps);
+            // sqrt, 1 / h, 1 / d and exp through the hardware instructions (v_sqrt_f32, v_rcp_f32, v_exp_f32: 1 ulp each)
+            // instead of the IEEE expansions (~10 dependent instructions per divide / sqrt, ~15 per expf; -DIFD_EXACT_REP
+            // brings them back): -1.3 % of the kernel on the bench workload, and the hot kernel's gradient stays at
+            // 3.6e-7 ... 6.4e-7 of the reference gradient's maximum (4e-7 ... 6e-7 with the expansions) - the f32 rounding
+            // of the terms themselves dominates.
+#ifndef IFD_EXACT_REP
+            const float d = __builtin_amdgcn_sqrtf(d2);
+            const float ih = __builtin_amdgcn_rcpf(rc.h);
+            const float q = d * ih;
+            const float w = __expf(-(q * q));
+            (s ? lb : la) += (rc.radius - d) * w;
+            const float dd = -w - (rc.radius - d) * w * (2.f * q * ih);
+            const float coef = d2raw > rc.eps ? dd * __builtin_amdgcn_rcpf(d) : 0.f;
+#else
             const float d = sqrtf(d2);
             const float q = d / rc.h;
             const float w = expf(-(q * q));
             (s ? lb : la) += (rc.radius - d) * w;
             const float dd = -w - (rc.radius - d) * w * (2.f * q / rc.h);
             const float coef = d2raw > rc.eps ? dd / d : 0.f;
+#endif
             f[s][0] = fix32(coef * ex);
             f[s][1] = fix32(coef * ey);
             f[s][2] = fix32(coef * ez);
@@ -884,8 +899,8 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
                 float& vr = vv[3 * q + a];
                 mr = mr + (g - mr) * (1.f - 0.9f);
                 vr = vr * 0.999f + (1.f - 0.999f) * g * g;
-                // sqrt(v) / bc2 + eps and m / denom through v_sqrt_f32 / v_rcp_f32 (1 ulp each): the update differs from
-                // torch's by ~1e-7 of ITS size (~1e-10 absolute), the moments themselves are exact
+                // IEEE sqrt and divisions, like torch's kernels (the hardware v_sqrt_f32 / v_rcp_f32 forms measured -0.25 %
+                // of the kernel on the bench workload: not taken for the update itself)
                 const float denom = sqrtf(vr) / bc2 + 1e-8f;
                 const float upd = step_size * (mr / denom);
                 xs[a] = xs[a] - upd;
