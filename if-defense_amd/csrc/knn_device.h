@@ -346,6 +346,8 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
         KnnPt& kp = half ? kb : ka;
         const float d4 = half ? d4b : d4a;
         const float my_tf = d4 * kp.al_f, my_tb = d4 * kp.al_b;
+        int r_nf = 0, r_nb = 0;
+        float r_tf = 0.f, r_tb = 0.f;
         unsigned long long mask = __ballot(half ? need_b : need_a);
 #pragma unroll 1
         while (mask != 0ull) {
@@ -368,29 +370,35 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
                 if (n_in - nf_new > 0.85f * LIST_B) tb *= (nf_new + 0.75f * LIST_B) / n_in;
                 tb = fmaxf(tb, tf);
             }
-            if (lane == l) {
-                kp.cnt_f = min(nf, LIST_F);
-                kp.rho_f = nf <= LIST_F ? sqrtf(tf) : 0.f;          // front complete only if everything fitted
-                kp.cnt_b = nb <= LIST_B ? nb : -1;
-                kp.rho_b = sqrtf(tb);
-                // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly when sparse
-                if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb / d4; }
+            // the owning lane only records the outcome (four moves); its state is derived from it once, after the loop,
+            // by all owners at the same time - inside the loop the square roots and divides below cost the whole wave
+            // ~70 instructions per target for one lane's benefit
+            if (lane == l) { r_nf = nf; r_nb = nb; r_tf = tf; r_tb = tb; }
+        }
+        if (half ? need_b : need_a) {
+            const int nf = r_nf, nb = r_nb;
+            const float tf = r_tf, tb = r_tb;
+            kp.cnt_f = min(nf, LIST_F);
+            kp.rho_f = nf <= LIST_F ? sqrtf(tf) : 0.f;          // front complete only if everything fitted
+            kp.cnt_b = nb <= LIST_B ? nb : -1;
+            kp.rho_b = sqrtf(tb);
+            // carry the (possibly shrunk) radii forward as multiples of the 5-NN bound; grow slowly when sparse
+            if (d4 > 0.f) { kp.al_f = tf / d4; kp.al_b = tb / d4; }
 #ifndef IFD_FILL_Q
 #define IFD_FILL_Q 2          // grow a radius while its list is less than IFD_FILL_Q / 4 full
 #endif
-                if (4 * nf < IFD_FILL_Q * LIST_F) kp.al_f *= 1.15f;
-                if (4 * (nf + nb) < IFD_FILL_Q * LIST_M) kp.al_b *= 1.15f;
-                kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
-                kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
-                kp.al_f = fminf(kp.al_f, kp.al_b);
-                kp.x0 = xi;
-                kp.dbase = dbase;
-                // expected lifetime of the certificate ~ (rho - r5 - 6 mv) / (~2 mv per step)
+            if (4 * nf < IFD_FILL_Q * LIST_F) kp.al_f *= 1.15f;
+            if (4 * (nf + nb) < IFD_FILL_Q * LIST_M) kp.al_b *= 1.15f;
+            kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
+            kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
+            kp.al_f = fminf(kp.al_f, kp.al_b);
+            kp.x0 = X[(half ? OPT_THREADS : 0) + wave * 64 + lane];
+            kp.dbase = dbase;
+            // expected lifetime of the certificate ~ (rho - r5 - 6 mv) / (~2 mv per step)
 #ifndef IFD_FRAG_MULT
 #define IFD_FRAG_MULT 16.f
 #endif
-                kp.frag = kp.rho_b - sqrtf(d4) < IFD_FRAG_MULT * mv;
-            }
+            kp.frag = kp.rho_b - sqrtf(d4) < IFD_FRAG_MULT * mv;
         }
     }
 }
