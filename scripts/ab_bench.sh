@@ -7,7 +7,7 @@ for rep in 1 2; do
   for f in libifd_v_*.so; do
     cp "$f" libifd.so
     printf "%-32s " "$f"
-    python ../../bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-overlap 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('launch_ms', j['roofline']['launch_ms'], 'frac', j['roofline']['frac'])"
+    timeout 120 python ../../bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-overlap 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('launch_ms', j['roofline']['launch_ms'], 'frac', j['roofline']['frac'])"
   done
 done
 mv libifd_keep.so libifd.so
