@@ -516,7 +516,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : knn_list_bytes(B));
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
-    e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
+    e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
     if (large) {

@@ -48,6 +48,15 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+class AgreedFailure(RuntimeError):
+    """Raised on EVERY rank once an agreement point (`agree`) has reported a failure somewhere.  After it no rank
+    enters another collective: the ranks stop together.  `own` is this rank's exception (None on the healthy ranks)."""
+
+    def __init__(self, own=None):
+        super().__init__("a rank failed" if own is None else "%s: %s" % (type(own).__name__, own))
+        self.own = own
+
+
 def any_rank_failed(failed: bool, device=None) -> bool:
     """One MAX all-reduce of a status flag: True on every rank if any rank reports a failure (single process: `failed`)."""
     if not dist.is_initialized():
@@ -56,6 +65,16 @@ def any_rank_failed(failed: bool, device=None) -> bool:
     flag = torch.tensor([1.0 if failed else 0.0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     return bool(flag.item() > 0)
+
+
+def agree(err, device=None):
+    """Agreement point of the sharded drivers: every rank reports whether its local work since the last agreement
+    failed (`err`: the exception, or None).  If any rank failed, AgreedFailure is raised on all of them - BEFORE the next
+    data collective, so a rank that threw during its compute never leaves its peers waiting in an all-gather (mismatched
+    collectives hang on RCCL).  The protocol the drivers keep: exactly one agreement reports a failure (a rank that fails
+    anywhere calls the next agreement with its error), and nobody calls a collective after an agreement has failed."""
+    if any_rank_failed(err is not None, device):
+        raise AgreedFailure(err)
 
 
 def shutdown():
@@ -76,8 +95,9 @@ def gather_shards(local: torch.Tensor, n_total: int, per: int) -> torch.Tensor:
     return out[:n_total]
 
 
-def defend_sharded(defend: Callable[[np.ndarray, int, int], torch.Tensor], pc: np.ndarray) -> torch.Tensor:
-    """Run `defend(shard, cloud_index_base, total)` on this rank's contiguous shard of `pc` and all-gather.
+def defend_sharded(defend: Callable[[np.ndarray, int, int], torch.Tensor], pc: np.ndarray, device=None) -> torch.Tensor:
+    """Run `defend(shard, cloud_index_base, total)` on this rank's contiguous shard of `pc`, agree that every rank's
+    compute succeeded (`agree`: raises AgreedFailure everywhere if one did not), then all-gather.
 
     Because random draws are keyed by the global cloud index and the 1/B loss factor by the reference batch a
     cloud belongs to, the gathered array is bit-identical to a single-process run (tests/test_host_cpu.py,
@@ -87,5 +107,10 @@ def defend_sharded(defend: Callable[[np.ndarray, int, int], torch.Tensor], pc: n
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = len(pc)
     lo, hi, per = shard_range(n, rank, world)
-    local = defend(pc[lo:hi], lo, n)
+    local, err = None, None
+    try:
+        local = defend(pc[lo:hi], lo, n)
+    except Exception as e:                      # noqa: BLE001  (reported to every rank by the agreement below)
+        err = e
+    agree(err, device)
     return gather_shards(local, n, per)

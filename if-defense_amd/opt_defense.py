@@ -147,19 +147,23 @@ def validate_limits(args, cfg, files, model="convonet"):
         raise SystemExit("data.pointcloud_n %d: the encoder takes at most %d points per cloud" % (n_in, MAX_ENCODER_POINTS))
     if args.batch_size < 1 or args.iterations < 0:
         raise SystemExit("--batch_size must be >= 1 and --iterations >= 0")
+    shapes = {}
     for path in files:
         if not os.path.isfile(path):
             raise SystemExit("input file not found: %s" % path)
         npz = np.load(path)
+        shapes[path] = {}
         for key in (('train_pc', 'train_label', 'test_pc', 'test_label') if args.train else ('test_pc', 'test_label')):
             if key not in npz.files:
                 raise SystemExit("%s: missing array %r" % (path, key))
         for key in (('train_pc', 'test_pc') if args.train else ('test_pc',)):
             shp = npz[key].shape
+            shapes[path][key] = tuple(shp)
             if len(shp) != 3 or shp[2] < 3:
                 raise SystemExit("%s: %s must be [N, K, >= 3], got %s" % (path, key, (shp,)))
             if shp[1] > MAX_INPUT_POINTS or shp[1] < 6:
                 raise SystemExit("%s: %s has %d points per cloud; this build takes 6 ... %d" % (path, key, shp[1], MAX_INPUT_POINTS))
+    return shapes
 
 
 def main(argv=None, model="convonet", restorer_factory=None, backend=None, device=None):
@@ -169,7 +173,7 @@ def main(argv=None, model="convonet", restorer_factory=None, backend=None, devic
     cfg = load_config(args.config, 'configs/default.yaml', model)
     check_supported(cfg, model)
     files = list_inputs(args.data_root, args.train)
-    validate_limits(args, cfg, files, model)
+    shapes = validate_limits(args, cfg, files, model)
 
     import torch
     from . import DefenseArgs, defend_npz_test_data, defend_npz_train_test_data, defend_point_cloud
@@ -193,14 +197,32 @@ def main(argv=None, model="convonet", restorer_factory=None, backend=None, devic
                         input_npoint=cfg['data']['pointcloud_n'], seed=args.seed)
 
     def defend(pc):
+        # compute the local shard -> agreement (raises D.AgreedFailure on every rank if one rank's compute failed) -> all-gather
         out = D.defend_sharded(lambda shard, base, total: defend_point_cloud(r, shard, dargs, base, total,
-                                                                             return_device=True), pc)
+                                                                             return_device=True), pc, device)
         return out.cpu().numpy()
 
+    def stop(path, own):
+        if own is not None:
+            raise SystemExit("rank %d failed on %s: %s: %s" % (rank, path, type(own).__name__, own))
+        raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
+
+    def settle(path, err):
+        """The agreement that closes a file (after rank 0's write).  A rank whose failure happened OUTSIDE an agreement
+        (loading the file, the write) reports it here - for its peers this call is whatever agreement they reach next, all
+        agreements being the same one-element MAX all-reduce - and a rank that already left an agreement with
+        AgreedFailure enters no further collective (D.agree's protocol): the ranks stop together, none of them inside an
+        all-gather the failed rank never reaches."""
+        if isinstance(err, D.AgreedFailure):
+            stop(path, err.own)
+        try:
+            D.agree(err, device)
+        except D.AgreedFailure as e:
+            stop(path, e.own)
+
     def one_file(path):
-        """Every rank restores its shards (the all-gathers inside `defend` are collective), rank 0 writes the file.  A
-        failure on one rank (unwritable output, a bad array) must not leave the others waiting in the next file's
-        all-gather: the ranks agree on a status after every file and stop together."""
+        """Every rank restores its shards, rank 0 writes the file.  Collectives per array: one agreement, one all-gather
+        (inside `defend`); per file: one closing agreement."""
         fn = defend_npz_train_test_data if args.train else defend_npz_test_data
         err = None
         try:
@@ -210,37 +232,39 @@ def main(argv=None, model="convonet", restorer_factory=None, backend=None, devic
                 npz = np.load(path)
                 for key in (('train_pc', 'test_pc') if args.train else ('test_pc',)):
                     defend(npz[key][..., :3])
-        except Exception as e:                  # noqa: BLE001  (reported below, on every rank)
+        except Exception as e:                  # noqa: BLE001  (reported on every rank by settle)
             err = e
-        bad = D.any_rank_failed(err is not None, device)
-        if err is not None:
-            raise SystemExit("rank %d failed on %s: %s: %s" % (rank, path, type(err).__name__, err))
-        if bad:
-            raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
+        settle(path, err)
 
     if len(files) > 1 and not args.train:
         # a directory of files (opt_defense.py:380-385): one stream of device passes - the SOR / preprocess / encoder
         # kernels of file n + 1 run on a second HIP stream under the tail of file n's optimiser (pipeline.defend_stream),
-        # and under rank 0's device-to-host copy and np.savez of file n
-        from . import defend_stream, get_save_name
+        # and under rank 0's device-to-host copy and np.savez of file n.  Files are loaded on demand, one ahead.
+        from . import defend_stream
         from .dist import gather_shards, shard_range
-        arrays = [np.load(f)['test_pc'][..., :3] for f in files]
-        ranges = [shard_range(len(a), rank, world) for a in arrays]
-        shards = [a[lo:hi] for a, (lo, hi, per) in zip(arrays, ranges)]
-        stream = defend_stream(r, shards, dargs, bases=[lo for lo, hi, per in ranges], totals=[len(a) for a in arrays])
-        for path, a, (lo, hi, per), local_out in zip(files, arrays, ranges, stream):
+        lens = [shapes[f]['test_pc'][0] for f in files]
+        ranges = [shard_range(n, rank, world) for n in lens]
+
+        def shards():
+            for f, (lo, hi, per) in zip(files, ranges):
+                yield np.load(f)['test_pc'][lo:hi, :, :3]
+
+        stream = iter(defend_stream(r, shards(), dargs, bases=[lo for lo, hi, per in ranges], totals=lens))
+        for path, n, (lo, hi, per) in zip(files, lens, ranges):
             err = None
             try:
-                out = gather_shards(local_out, len(a), per).cpu().numpy()
+                local_out, cerr = None, None
+                try:
+                    local_out = next(stream)    # this rank's compute (and the load / pre-processing of the next file)
+                except Exception as e:          # noqa: BLE001
+                    cerr = e
+                D.agree(cerr, device)           # before the all-gather: a rank that threw must not leave its peers in it
+                out = gather_shards(local_out, n, per).cpu().numpy()
                 if rank == 0:
                     defend_npz_test_data(r, path, dargs, defend=lambda pc, out=out: out)
             except Exception as e:              # noqa: BLE001
                 err = e
-            bad = D.any_rank_failed(err is not None, device)
-            if err is not None:
-                raise SystemExit("rank %d failed on %s: %s: %s" % (rank, path, type(err).__name__, err))
-            if bad:
-                raise SystemExit("rank %d stops: another rank failed on %s" % (rank, path))
+            settle(path, err)
     else:
         for one in files:
             one_file(one)

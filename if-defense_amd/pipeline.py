@@ -61,55 +61,77 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
     the tail frees instead of after it.  Results are bit-identical to the serial order: every kernel is deterministic and
     the passes share nothing but read-only weights (the context's encoder scratch is used by one pass at a time: the
     side stream's work is ordered, and the optimiser uses the separate neighbour-list scratch).
+
+    Lazy: ``arrays`` may be a generator (the CLI loads the files of a directory on demand).  Array i + 1 is pulled,
+    uploaded and given its output tensor only when its first device pass is about to be prepared - one pass ahead of the
+    optimiser - and array i's input is dropped once its last pass has been prepared, so host and device memory hold two
+    files at a time, not the directory.
     """
-    arrays = list(arrays)
-    n_arr = len(arrays)
-    bases = [0] * n_arr if bases is None else list(bases)
-    totals = [None] * n_arr if totals is None else list(totals)
-    units = []                                    # (array index, lo, hi): one device pass each
-    xs = []
-    for i, pc in enumerate(arrays):
-        x = torch.as_tensor(pc)[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
-        xs.append(x)
-        for lo in range(0, max(x.shape[0], 1), int(args.chunk)):
-            units.append((i, lo, min(x.shape[0], lo + int(args.chunk))))
-    outs = [torch.empty(x.shape[0], args.sample_npoint, 3, device=r.device, dtype=torch.float32) for x in xs]
+    bases = None if bases is None else list(bases)
+    totals = None if totals is None else list(totals)
     on_gpu = torch.device(r.device).type == "cuda"           # (the host tests drive this with a stand-in model on the CPU)
     main = torch.cuda.current_stream(r.device) if on_gpu else None
-    side = torch.cuda.Stream(r.device) if (on_gpu and overlap and len(units) > 1) else None
-    if side is not None:
-        side.wait_stream(main)                    # the inputs are resident; from here on the side stream only follows itself
+    side = None
+
+    def units():
+        """(array index, holder of the array's input / output tensors, lo, hi, last pass of its array), one device pass each"""
+        for i, pc in enumerate(arrays):
+            n = int(pc.shape[0])
+            h = {"pc": pc, "x": None, "out": torch.empty(n, args.sample_npoint, 3, device=r.device, dtype=torch.float32)}
+            los = list(range(0, max(n, 1), int(args.chunk)))
+            for lo in los:
+                yield i, h, lo, min(n, lo + int(args.chunk)), lo == los[-1]
+
+    def upload(h):
+        """the array's points on the device - copied on the CURRENT stream (the side stream when passes overlap: a copy
+        enqueued on the main stream would wait behind the optimiser launch it is supposed to run under)"""
+        if h["x"] is None:
+            h["x"] = torch.as_tensor(h["pc"])[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
+            h["pc"] = None
+        return h["x"]
 
     def launch_prepare(u):
-        i, lo, hi = u
-        total = int(totals[i] if totals[i] is not None else bases[i] + xs[i].shape[0])
+        i, h, lo, hi, last = u
+        base = 0 if bases is None else bases[i]
+        total = int(totals[i] if (totals is not None and totals[i] is not None) else base + h["out"].shape[0])
         if hi <= lo:
             return None
         if side is None:
-            return _prepare_unit(r, xs[i][lo:hi], args, bases[i] + lo, total) + (None,)
-        with torch.cuda.stream(side):             # (side-stream order keeps the passes' use of the encoder scratch apart)
-            init, planes, lb = _prepare_unit(r, xs[i][lo:hi], args, bases[i] + lo, total)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        for t in (init, planes, lb):              # consumed on the main stream: keep the allocator from recycling them early
-            t.record_stream(main)
-        return init, planes, lb, ev
+            res = _prepare_unit(r, upload(h)[lo:hi], args, base + lo, total) + (None,)
+        else:
+            with torch.cuda.stream(side):         # (side-stream order keeps the passes' use of the encoder scratch apart)
+                init, planes, lb = _prepare_unit(r, upload(h)[lo:hi], args, base + lo, total)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for t in (init, planes, lb):          # consumed on the main stream: keep the allocator from recycling them early
+                t.record_stream(main)
+            res = (init, planes, lb, ev)
+        if last:
+            h["x"] = None                         # the input is not needed beyond its last pass's pre-processing
+        return res
 
-    ready = launch_prepare(units[0]) if units else None
-    done = 0
-    for k, (i, lo, hi) in enumerate(units):
-        cur = ready
-        if cur is not None:
-            init, planes, lb, ev = cur
+    it = units()
+    cur_u = next(it, None)
+    if cur_u is None:
+        return
+    nxt_u = next(it, None)
+    if on_gpu and overlap and nxt_u is not None:
+        side = torch.cuda.Stream(r.device)
+        side.wait_stream(main)                    # inputs already on the device were produced on the main stream
+    ready = launch_prepare(cur_u)
+    while cur_u is not None:
+        i, h, lo, hi, last = cur_u
+        if ready is not None:
+            init, planes, lb, ev = ready
             if ev is not None:
                 main.wait_event(ev)
-            outs[i][lo:hi] = r.optimize_points(init, planes, rep_weight=args.rep_weight, iterations=args.iterations,
-                                               lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing)
-        ready = launch_prepare(units[k + 1]) if k + 1 < len(units) else None       # rides on the optimiser's tail
-        del cur
-        while done < n_arr and (k + 1 == len(units) or units[k + 1][0] > done):
-            yield outs[done]
-            done += 1
+            h["out"][lo:hi] = r.optimize_points(init, planes, rep_weight=args.rep_weight, iterations=args.iterations,
+                                                lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing)
+        ready = launch_prepare(nxt_u) if nxt_u is not None else None               # rides on the optimiser's tail
+        if last:
+            yield h["out"]
+        del h, cur_u
+        cur_u, nxt_u = nxt_u, (next(it, None) if nxt_u is not None else None)
 
 
 def defend_point_cloud(r: Restorer, pc, args: DefenseArgs, cloud_index_base: int = 0, total_clouds: Optional[int] = None,

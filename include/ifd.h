@@ -24,6 +24,13 @@
  *     makes that device current for the duration of the call and restores the
  *     caller's (launches and workspace never land on another GPU).  One thread
  *     at a time per context; different contexts are independent (no hidden globals).
+ *   - a context owns mutable scratch that its calls use on the caller's stream: the
+ *     optimise calls (ifd_optimize / ifd_onet_optimize) share the neighbour lists, the
+ *     Adam table and the counters; the encoder calls (ifd_encode_* / ifd_unet /
+ *     ifd_onet_encode) share the encoder scratch.  Calls of one kind on one context
+ *     must therefore be stream-ordered with each other (one stream per kind, or
+ *     events between them); an optimise call and an encoder call may overlap on
+ *     two streams (pipeline.defend_stream does exactly that).
  *
  * Plane layout used on the device ("channel-last"):
  *     planes[b][plane][row][col][ch],  plane in {0:xz, 1:xy, 2:yz}, row = u1 cell,

@@ -1,0 +1,42 @@
+#!/bin/bash
+# Issue-side PMC counters of ifd::optimize_kernel ON THE BENCH WORKLOAD (the 2468-cloud launch of `bench.py --steps 1`:
+# real encoder planes of the synthetic clouds), one JSON file.  Separate rocprofv3 --pmc passes, kernel trace only.
+#   bash scripts/pmc_bench.sh <tag> [clouds]  -> gpurun_out/pmc_bench_<tag>.json
+TAG=${1:-x}
+CLOUDS=${2:-2468}
+R=$(pwd)
+OUT=$R/gpurun_out/pmc_bench_$TAG
+CMD="python $R/bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline --no-overlap"
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pass$i -o p -- $CMD > $OUT/pass$i.json 2> $OUT/pass$i.err
+done
+cd $R
+python - <<PY
+import csv, glob, json, collections
+acc = collections.defaultdict(float)
+clouds = $CLOUDS
+for f in glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "ifd::optimize_kernel" in r["Kernel_Name"]]
+    if not rows:
+        continue
+    big = max(int(r["Grid_Size"]) for r in rows)
+    disp = sorted({r["Dispatch_Id"] for r in rows if int(r["Grid_Size"]) == big})[-1]
+    for r in rows:
+        if r["Dispatch_Id"] == disp:
+            acc[r["Counter_Name"]] += float(r["Counter_Value"])
+a = dict(acc)
+waves = clouds * 8
+if a.get("SQ_WAVE_CYCLES"):
+    # SQ_WAVE_CYCLES counts in units of 4 cycles; two waves share a SIMD, so SIMD-resident cycles = wave cycles / 2
+    a["cycles_per_step_per_wave"] = a["SQ_WAVE_CYCLES"] * 4 / waves / 501
+    a["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["SQ_WAVE_CYCLES"] * 4 / 2) if a.get("SQ_VALU_MFMA_BUSY_CYCLES") else None
+    a["valu_non_mfma_per_simd_step"] = (a.get("SQ_INSTS_VALU", 0) - a.get("SQ_INSTS_MFMA", 0)) / (clouds * 4) / 501
+    a["valu_to_mfma"] = (a.get("SQ_INSTS_VALU", 0) - a.get("SQ_INSTS_MFMA", 0)) / max(1.0, a.get("SQ_INSTS_MFMA", 0))
+a["command"] = "bash scripts/pmc_bench.sh $TAG $CLOUDS: separate rocprofv3 --pmc passes over bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline --no-overlap (one optimize_kernel launch of $CLOUDS clouds x 501 steps on the bench workload)"
+json.dump(a, open("$R/gpurun_out/pmc_bench_$TAG.json", "w"), indent=1)
+print(json.dumps(a, indent=1))
+PY

@@ -191,6 +191,10 @@ class FakeRestorer:
         return sel.sum(dim=(1, 2))
 
     def optimize_points(self, init, planes, rep_weight, iterations, lr, loss_batch, normalize, **kw):
+        if os.environ.get("FAKE_FAIL_RANK") == os.environ.get("RANK", "0"):      # a kernel / IfdError on ONE rank, mid-compute
+            self.n_calls = getattr(self, "n_calls", 0) + 1
+            if self.n_calls > int(os.environ.get("FAKE_FAIL_AFTER", "0")):
+                raise RuntimeError("injected compute failure")
         return init + planes[:, None, None] * 1e-3 + loss_batch.float()[:, None, None] * 1e-2 + iterations
 
 
@@ -200,7 +204,7 @@ open(os.path.join(%(out)r, "done_rank%%s" %% os.environ.get("RANK", "0")), "w").
 '''
 
 
-def _run_cli(tmp_path, world, argv, expect_ok=True):
+def _run_cli(tmp_path, world, argv, expect_ok=True, extra_env=None):
     import socket
     script = tmp_path / "cli_run.py"
     script.write_text(_CLI_SCRIPT % {"root": ROOT, "out": str(tmp_path)})
@@ -213,7 +217,7 @@ def _run_cli(tmp_path, world, argv, expect_ok=True):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, **(extra_env or {}))
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                             "--master-addr", "127.0.0.1", "--master-port", port, str(script)] + argv,
                            capture_output=True, text=True, env=env, timeout=300)
@@ -304,3 +308,32 @@ def test_cli_failing_write_stops_every_rank(tmp_path):
     assert r.returncode != 0
     assert not list(tmp_path.glob("done_rank*")), r.stdout + r.stderr
     assert "failed on" in (r.stdout + r.stderr) and "another rank failed" in (r.stdout + r.stderr), r.stdout + r.stderr
+
+
+def test_cli_compute_failure_on_one_rank_stops_every_rank_before_the_gather(tmp_path):
+    """A non-zero rank throws DURING its compute (a kernel error, an IfdError): its peers must not be left inside the
+    all-gather it never reaches (mismatched collectives hang on RCCL) - the ranks agree on a status BEFORE every gather and
+    stop together, within seconds.  Both drivers: one file, and a directory through the streamed driver (failing on the
+    second file, after a first successful gather)."""
+    import time
+    src = tmp_path / "adv.npz"
+    np.savez(src, test_pc=np.zeros((5, 40, 3), np.float32), test_label=np.arange(5))
+    t0 = time.time()
+    r = _run_cli(tmp_path, 2, ["--data_root", str(src), "--iterations=1", "--sample_npoint=16"], expect_ok=False,
+                 extra_env={"FAKE_FAIL_RANK": "1"})
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and not list(tmp_path.glob("done_rank*")), out
+    assert "rank 1 failed on" in out and "injected compute failure" in out and "rank 0 stops: another rank failed" in out, out
+    assert not (tmp_path / "ConvONet-Opt" / "convonet_opt-adv.npz").exists()
+    d = tmp_path / "dir"
+    d.mkdir()
+    for n in ("a.npz", "b.npz", "c.npz"):
+        np.savez(d / n, test_pc=np.ones((4, 40, 3), np.float32), test_label=np.arange(4))
+    r = _run_cli(tmp_path, 2, ["--data_root", str(d), "--iterations=1", "--sample_npoint=16"], expect_ok=False,
+                 extra_env={"FAKE_FAIL_RANK": "1", "FAKE_FAIL_AFTER": "1"})
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and not list(tmp_path.glob("done_rank*")), out
+    assert "rank 1 failed on" in out and "rank 0 stops: another rank failed" in out, out
+    assert (d / "ConvONet-Opt" / "convonet_opt-a.npz").exists()          # the first file went through before the failure
+    assert not (d / "ConvONet-Opt" / "convonet_opt-c.npz").exists()
+    assert time.time() - t0 < 120, "the ranks did not stop promptly"
