@@ -696,7 +696,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_optimize workspace", e);
     float* ab = nullptr;
     e = onet_fold(ctx, c, B, s, &ab);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, IFD_N_COUNTERS * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, s);
     if (e == hipSuccess)
         e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,

@@ -61,7 +61,10 @@ def any_rank_failed(failed: bool, device=None) -> bool:
     """One MAX all-reduce of a status flag: True on every rank if any rank reports a failure (single process: `failed`)."""
     if not dist.is_initialized():
         return bool(failed)
-    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    if dist.get_backend() == "nccl":            # RCCL reduces device tensors only
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
     flag = torch.tensor([1.0 if failed else 0.0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     return bool(flag.item() > 0)
