@@ -95,6 +95,7 @@ struct ifd_ctx {
     size_t ws_enc_bytes = 0;
     DecConst dc{};
     unsigned long long* d_counters = nullptr;   // IFD_N_COUNTERS diagnostic counters of the last ifd_optimize
+    int n_cu = 256;                // compute units of the device (rounds of the persistent optimiser)
     void* ws = nullptr;            // context-owned scratch (kNN lists, encoder activations), grown on demand
     size_t ws_bytes = 0;
     void* adam_tab = nullptr;      // per-step Adam bias corrections of the current optimise call (launch_adam_table)
@@ -340,6 +341,10 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     ctx->dc.sdiv = (float)(1.0 + (double)cfg->padding + 10e-6);
     ctx->dc.uclamp = (float)(1.0 - 10e-6);
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_dec_img), DEC_FLOATS * sizeof(float));
     if (e == hipSuccess) {
         std::vector<float> img = build_dec_image(ctx->w.data());
@@ -509,11 +514,14 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     OptArgs a{};
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
     a.knn_scan_every_step = prm->knn_scan_every_step;
+    a.planes_shared = prm->planes_shared;
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;
+    if (prm->split != 0 && prm->split != 1 && prm->split != 2 && prm->split != 4)
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: split must be 0 (automatic), 1, 2 or 4");
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (optimize.hip)
-    hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : knn_list_bytes(B));
+    hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : optimize_ws_bytes(B));
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
     e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
@@ -524,8 +532,8 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
                                   static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
     }
-    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, static_cast<uint16_t*>(ctx->ws), ctx->d_counters,
-                        static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
+    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
+                        static_cast<const float*>(ctx->adam_tab), B, K, a, prm->split, ctx->n_cu, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
 }
 

@@ -7,7 +7,7 @@
 namespace ifd {
 
 struct OptArgs {
-    int steps, t0, loss_batch, normalize, knn_scan_every_step;
+    int steps, t0, loss_batch, normalize, knn_scan_every_step, planes_shared;
     float lr, rep_weight, threshold, rep_radius, rep_h, rep_eps;
     DecConst dc;
 };
@@ -43,9 +43,11 @@ hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, co
                           int32_t* n_kept, float* proc_out, hipStream_t s);
 
 hipError_t configure_optimize_kernels();
+// ws: optimize_ws_bytes(B) of context workspace; split: ifd_opt_params.split; n_cu: compute units of the device
 hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                           const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters,
-                           const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s);
+                           const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
+                           const float* adam_tab, int B, int K, const OptArgs& a, int split, int n_cu, hipStream_t s);
+size_t optimize_ws_bytes(int B);
 // per-step Adam bias corrections {lr / (1 - beta1^t), sqrt(1 - beta2^t)}, t = t0 + 1 ... t0 + steps -> tab[steps][2]
 hipError_t launch_adam_table(float* tab, int t0, int steps, float lr, hipStream_t s);
 // bytes of context workspace ifd_optimize needs for B clouds (certified neighbour lists)

@@ -561,13 +561,69 @@ __device__ __forceinline__ void unpack_xy(long long s, int& x, int& y) {
     x = (int)((s - (long long)y) >> 32);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split clouds (optimize.hip, "cooperative mode"): S = 2 or 4 workgroups - on as many CUs - share one cloud.  Member m owns
+// the points {vt, vt + 512 : vt in [m * 512 / S, (m + 1) * 512 / S)}: their neighbour lists, their repulsion terms, their
+// decoder tiles and their Adam update; every member keeps the whole cloud's positions in its LDS.  What crosses CUs goes
+// through this per-cloud block of global memory: neighbour terms of points another member owns (fixed-point integer atomics:
+// the total is the same integer whatever the order or the split), the updated positions, the displacement maxima of the
+// neighbour-list certificates, and two monotonic arrival counters.
+// Memory ordering: EVERY access to this block is an agent-scope atomic (coherent across the XCDs' L2s by itself: sc1
+// write-through stores / sc1 loads), so publishing needs no cache write-back or invalidate - a member makes its stores
+// and atomics complete (coop_publish: s_waitcnt vmcnt(0), which on gfx9 also covers stores; a workgroup-scope release fence
+// is exactly that, and a compiler barrier) before it arrives at a counter, and a member that has seen the counter reads
+// the data with agent-scope loads.  (A formal agent-scope release / acquire pair adds an L2 write-back of everything the
+// XCD has dirtied - the parked scratch state of 32 workgroups - and an invalidate: 35 us per step, measured.)
+// ---------------------------------------------------------------------------------------------
+struct CoopWs {
+    f32x4 X[MAXK];                    // positions after the last Adam step (written by the owners)
+    long long Fxy[MAXK];              // neighbour terms received from other members, packed like RepAcc
+    int Fz[MAXK];
+    float L[MAXK][2];                 // last step only: BCE term, repulsion term of every point
+    float scal[8][2];                 // per (virtual) owner wave: displacement maximum, step-length maximum of the next step
+    int flag[4];                      // per member: whole-cloud list rebuild requested
+    unsigned int bar_knn, bar_step;   // arrivals: owner waves that finished their kNN phase; members that finished their step
+    unsigned int pad[2];
+};
+struct CoopView {
+    CoopWs* ws;
+    int member;
+};
+template <int S>
+__device__ __forceinline__ bool coop_owns(int j, int member) {
+    return S == 1 || ((j & (OPT_THREADS - 1)) / (OPT_THREADS / S)) == member;
+}
+__device__ __forceinline__ float coop_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coop_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coop_publish() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void coop_arrive(unsigned int* ctr) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coop_wait(unsigned int* ctr, unsigned int target) {      // (call it wave-uniformly)
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// one neighbour (or centre) term into the accumulators of point j: LDS if this workgroup owns j, else the owner's global ones
+template <int S>
+__device__ __forceinline__ void rep_scatter(const RepAcc F, const CoopView cv, int j, int fx, int fy, int fz) {
+    if (coop_owns<S>(j, cv.member)) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + j), (unsigned long long)pack_xy(fx, fy));
+        atomicAdd(F.z + j, fz);
+    } else {
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cv.ws->Fxy + j), (unsigned long long)pack_xy(fx, fy),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cv.ws->Fz + j, fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // The two owned points together (optimiser): one instruction stream with the two independent chains interleaved -
 // two rep_point calls under separate `if (p < K)` branches cannot overlap their LDS / sqrt / exp / divide latencies.
 // The centre's own share (minus what its five neighbours receive) goes into F with the same fixed-point atomics: integer
 // addition commutes, so F[i] ends up as the same sum whatever the order, and no register has to carry it to the Adam phase.
+template <int S = 1>
 __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
                                            const Top5& ta, const Top5& tb, const RepConst rc, float& loss_a,
-                                           float& loss_b) {
+                                           float& loss_b, const CoopView cv = CoopView{nullptr, 0}) {
     const bool va = pa < K, vb = pb < K;
     const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
     const int ia[5] = {ta.i0, ta.i1, ta.i2, ta.i3, ta.i4}, ib[5] = {tb.i0, tb.i1, tb.i2, tb.i3, tb.i4};
@@ -611,13 +667,11 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const Re
         }
         if (va) {
             gca[0] -= f[0][0]; gca[1] -= f[0][1]; gca[2] -= f[0][2];
-            atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + ja), (unsigned long long)pack_xy(f[0][0], f[0][1]));
-            atomicAdd(F.z + ja, f[0][2]);
+            rep_scatter<S>(F, cv, ja, f[0][0], f[0][1], f[0][2]);
         }
         if (vb) {
             gcb[0] -= f[1][0]; gcb[1] -= f[1][1]; gcb[2] -= f[1][2];
-            atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + jb), (unsigned long long)pack_xy(f[1][0], f[1][1]));
-            atomicAdd(F.z + jb, f[1][2]);
+            rep_scatter<S>(F, cv, jb, f[1][0], f[1][1], f[1][2]);
         }
     }
     if (va) {
@@ -708,11 +762,13 @@ struct KnnShared {
 
 // kNN + repulsion of the two points (pa, pb) this lane owns, for one optimiser step (all lanes of an owner wave call
 // it together).  Leaves the loss terms in rep_loss_a/b and scatters the neighbour AND centre gradients into F (fixed point).
+// `wave` is the wave's index among the cloud's eight owner waves (= its index in the workgroup unless the cloud is split).
+template <int S = 1>
 __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
                                           int wave, int lane, int step, bool last, bool scan_every_step,
                                           const uint16_t* La, const uint16_t* Lb, uint16_t* cloud_lists, KnnPt& ka,
                                           KnnPt& kb, const KnnShared& sh, const RepConst rc, float& rep_loss_a,
-                                          float& rep_loss_b, KnnCounters& cn) {
+                                          float& rep_loss_b, KnnCounters& cn, const CoopView cv = CoopView{nullptr, 0}) {
     float* const dmaxbuf = sh.dmaxbuf;
     float* const movebuf = sh.movebuf;
     volatile int* const rebuild_flag = sh.rebuild_flag;
@@ -726,7 +782,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
         const bool force = step == 0 || rebuild_flag[step & 1] != 0;      // block-uniform
         float dmax = 0.f, mv = 0.f;
 #pragma unroll
-        for (int w = 0; w < OWN_WAVES; ++w) {
+        for (int w = 0; w < (S > 1 ? MAX_WAVES : OWN_WAVES); ++w) {      // (split clouds: slots 8 ... hold the other members' maxima)
             dmax = fmaxf(dmax, dmaxbuf[(step & 1) * MAX_WAVES + w]);
             mv = fmaxf(mv, movebuf[(step & 1) * MAX_WAVES + w]);
         }
@@ -861,7 +917,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
         if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
         PROF_ACC(pc_eval);
     }
-    rep_point2(X, F, K, pa, pb, ta, tb, rc, rep_loss_a, rep_loss_b);
+    rep_point2<S>(X, F, K, pa, pb, ta, tb, rc, rep_loss_a, rep_loss_b, cv);
     PROF_ACC(pc_rep);
 }
 
@@ -875,9 +931,11 @@ struct AdamState {
 // and bc2 = sqrt(1 - beta2^t) come from a per-step table the host computes in double like torch's Python scalars
 // (adam_table in api.cpp).  Also reduces this wave's displacement / step-length maxima for the neighbour-list
 // certificates of the next step.
+template <int S = 1>
 __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* __restrict__ G, const RepAcc F,
                                            int K, int pa, int pb, float step_size, float bc2, float rep_scale,
-                                           AdamState& st, float (&xnew)[2][3], float& mv2_out) {
+                                           AdamState& st, float (&xnew)[2][3], float& mv2_out,
+                                           const CoopView cv = CoopView{nullptr, 0}) {
     float (&mm)[6] = st.mm;
     float (&vv)[6] = st.vv;
     // ---- Adam (torch/optim/adam.py _single_tensor_adam: lerp form, eps added after the bias-
@@ -894,8 +952,14 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             float xs[3] = {x.x, x.y, x.z};
             float msq = 0.f;
             int fi[3];
-            unpack_xy(F.xy[pt], fi[0], fi[1]);
+            long long fxy = F.xy[pt];
             fi[2] = F.z[pt];
+            if (S > 1) {        // what the other members' points sent here: integer sums, the same total as in one workgroup
+                fxy += (long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(cv.ws->Fxy + pt), 0ull,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fi[2] += __hip_atomic_exchange(cv.ws->Fz + pt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unpack_xy(fxy, fi[0], fi[1]);
             F.xy[pt] = 0;
             F.z[pt] = 0;
 #pragma unroll
@@ -917,6 +981,10 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             }
             mv2 = fmaxf(mv2, msq);
             X[pt] = f32x4{xs[0], xs[1], xs[2], 1.f};     // .w = 1: fc_p's bias input on the matrix pipe (optimize.hip)
+            if (S > 1) {
+                float* xg = reinterpret_cast<float*>(cv.ws->X + pt);
+                coop_st(xg, xs[0]); coop_st(xg + 1, xs[1]); coop_st(xg + 2, xs[2]);
+            }
         }
     }
     mv2_out = mv2;

@@ -624,7 +624,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
                     s2 = __builtin_elementwise_fma(f32x2{tap[t][1][mt][2 * h], tap[t][1][mt][2 * h + 1]}, wne2, s2);
                     s2 = __builtin_elementwise_fma(f32x2{tap[t][2][mt][2 * h], tap[t][2][mt][2 * h + 1]}, wsw2, s2);
                     s2 = __builtin_elementwise_fma(f32x2{tap[t][3][mt][2 * h], tap[t][3][mt][2 * h + 1]}, wse2, s2);
-                    const f32x2 cc = f32x2{c[t][4 * mt + 2 * h], c[t][4 * mt + 2 * h + 1]} + s2;
+                    const f32x2 cc = P == 0 ? s2 : f32x2{c[t][4 * mt + 2 * h], c[t][4 * mt + 2 * h + 1]} + s2;   // (c starts at 0)
                     c[t][4 * mt + 2 * h] = cc.x;
                     c[t][4 * mt + 2 * h + 1] = cc.y;
                 }
@@ -879,12 +879,25 @@ __device__ __forceinline__ void load_dec_image(float* __restrict__ W, const floa
 // ---------------------------------------------------------------------------------------------
 // NW waves per workgroup (8: 2 per SIMD / 256 VGPRs, 12: 3 per SIMD / 168 VGPRs); threads [0,512) own two points
 // each (kNN + Adam duty), every wave pulls 16-point decoder tiles from an LDS counter.
-template <int NW>
+//
+// S > 1: "split" clouds - S workgroups (S CUs) work on ONE cloud, so that a launch with fewer clouds than CUs (the last
+// partial round of a file, a small shard of a file spread over many GPUs) still fills the chip.  Member m of a cloud owns
+// 1024 / S points (CoopWs in knn_device.h): the threads [0, 512 / S) keep their neighbour lists, repulsion terms and Adam
+// state, and the member's waves run those points' decoder tiles.  Per step the members exchange: the neighbour terms of
+// points they do not own (integer atomics into the owner's global accumulators during the kNN phase, collected by the owner
+// in its Adam phase - arrival counter bar_knn, waited for under the decoder tiles), and the new positions + certificate
+// maxima (arrival counter bar_step, the one exposed cross-CU wait of a step).  Every sum that crosses members is an integer
+// sum or a maximum, the last step's loss reduction and the final normalisation are done on the whole cloud in the
+// one-workgroup order: the results are bit-identical to the S = 1 kernel.
+template <int NW, int S>
 __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float* __restrict__ dec_img, const float* __restrict__ planes, float* __restrict__ p,
     float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
     const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
-    unsigned long long* __restrict__ counters, const float* __restrict__ adam_tab, int K, OptArgs A) {
+    unsigned long long* __restrict__ counters, const float* __restrict__ adam_tab, int K, OptArgs A,
+    CoopWs* __restrict__ coop, int n_clouds) {
+    constexpr int OT = OPT_THREADS / S;               // owner threads of this workgroup (two points each)
+    constexpr int OW = OWN_WAVES / S;                 // ... and owner waves
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
     f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
@@ -895,13 +908,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     float* scratch = reinterpret_cast<float*>(F.z + MAXK);           // 128 floats
     f32x4* MV = reinterpret_cast<f32x4*>(scratch + 128);             // [3][OPT_THREADS] Adam moments of the owner threads
 
-    const int cloud = blockIdx.x;
+    // split clouds: the S members of a cloud sit 8 workgroups apart - consecutive workgroups go to the 8 XCDs in turn, so
+    // the members share an L2 (an optimisation only: every exchange is agent-scope)
+    const int cloud = S == 1 ? (int)blockIdx.x : (int)(((blockIdx.x >> 3) / S) * 8 + (blockIdx.x & 7));
+    const int member = S == 1 ? 0 : (int)((blockIdx.x >> 3) % S);
+    if (S > 1 && cloud >= n_clouds) return;
+    const CoopView cv = {S > 1 ? coop + cloud : nullptr, member};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
+    const float* pl = planes + (size_t)cloud * (A.planes_shared ? 0 : CLOUD_PLANE_FLOATS);
     float* pc = p + (size_t)cloud * K * 3;
-    const bool owner = tid < OPT_THREADS;
-    const int pa = owner ? tid : MAXK, pb = owner ? tid + OPT_THREADS : MAXK;   // the two points this thread owns
-    const int ntiles = (K + 31) >> 5;                                 // 32-point tiles (two 16-point sub-tiles)
+    const bool owner = tid < OT;
+    const int pa = owner ? member * OT + tid : MAXK, pb = owner ? member * OT + tid + OPT_THREADS : MAXK;   // the two points this thread owns
+    constexpr int NT = 32 / S, NTH = 16 / S;        // 32-point decoder tiles of this workgroup: NTH in each half of the cloud
+    auto tile_base = [&](int t) { return (t / NTH) * OPT_THREADS + member * OT + (t % NTH) * 32; };
 
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
@@ -916,7 +935,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #pragma unroll
             for (int a = 0; a < 3; ++a) ast.mm[3 * q + a] = ast.vv[3 * q + a] = 0.f;
             if (pt < K) {
-                X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 1.f};
+                if (S == 1) X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 1.f};
                 PIX[pt] = pix_encode(pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], A.dc);
                 if (A.t0 > 0 && m_io != nullptr) {
 #pragma unroll
@@ -930,6 +949,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         const KnnPt k0 = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false};   // ~10 front / ~35 total hits on a flat patch
         const int z = opaque_zero();
         if (owner) store_adam(MV, tid, ast);
+        if (S > 1)       // every member holds the whole cloud
+            for (int i = tid; i < K; i += NW * 64) X[i] = f32x4{pc[3 * i], pc[3 * i + 1], pc[3 * i + 2], 1.f};
         park_knnpt(park, z, PARK_KNN, k0);
         park_knnpt(park, z, PARK_KNN + 4, k0);
         park[z + PARK_KNN + 3] = f32x4{0.f, 0.f, 0.f, 0.f};          // rep_loss_a / rep_loss_b of the last step
@@ -955,7 +976,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     if (tid < 2) rebuild_flag[tid] = 0;
     if (tid == 0) *tile_ctr = 0;
     if (tid < CN_COUNT) lcnt[tid] = 0u;
-    if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
+    if (tid < 2 * MAX_WAVES) {      // (split clouds: slots [0, OW) this member's owner waves, [8, 16) the other members')
+        dmaxbuf[tid] = 0.f;
+        movebuf[tid] = (S == 1 || (tid & (MAX_WAVES - 1)) < OW || (tid & (MAX_WAVES - 1)) >= OWN_WAVES) ? 2.f * A.lr : 0.f;
+    }
     __syncthreads();
 #ifdef IFD_PROF
     unsigned long long* lprof = reinterpret_cast<unsigned long long*>(MV + 3 * OPT_THREADS);   // [NW][PC_COUNT] behind MV
@@ -972,23 +996,55 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         int tid_s = tid;
         asm volatile("" : "+v"(tid_s));
         const int lane = tid_s & 63, wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
-        const bool owner = tid_s < OPT_THREADS;
-        const int pa = owner ? tid_s : MAXK, pb = owner ? tid_s + OPT_THREADS : MAXK;
+        const bool owner = tid_s < OT;
+        const int pa = owner ? member * OT + tid_s : MAXK, pb = owner ? member * OT + tid_s + OPT_THREADS : MAXK;
 #if defined(IFD_PROF)
         KnnCounters cn{lcnt, lane, lprof + wave * PC_COUNT};
 #elif defined(IFD_TRACE)
         // time stamps of one step of cloud 0: [wave][32] behind the public counters; slot PC_KNN0 = step start, PC_BUILD /
         // PC_EVAL / PC_REP = ends of those kNN sub-phases, PC_TILE0 + n = end of the wave's n-th tile, PC_TILES = tile loop
         // left, PC_WAIT = barrier passed, PC_ADAM = Adam done
-        KnnCounters cn{lcnt, lane, (cloud == 0 && step == A.steps / 2 && counters != nullptr) ? counters + IFD_TRACE_BASE + wave * 32 : nullptr};
+        KnnCounters cn{lcnt, lane, (cloud == 0 && member == 0 && step == A.steps / 2 && counters != nullptr) ? counters + IFD_TRACE_BASE + wave * 32 : nullptr};
         PROF_ACC(PC_KNN0);
         int trace_tile = 0;
 #else
         KnnCounters cn{lcnt, lane};
 #endif
+        // Split clouds run the tiles FIRST and the owner waves' kNN phase at the end of the step: only 8 / S of a member's
+        // waves have neighbour duty, and a kNN wave beside a priority-1 tile wave is starved for a whole tile (measured: 100 k
+        // cycles for its 25 k of work) while that tile wave, without a partner that issues MFMAs, runs at little more than
+        // half the paired rate.  Measured at S = 2 / 4 (53 clouds x 501 steps, one S = 1 round: 84.7 ms): kNN first 52.0 /
+        // 36.0 ms, kNN first with the partner's first tile at the kNN wave's priority 55.7 / 34.8, tiles first 50.6 / 34.5.
+        // ---- decoder tiles, pulled from an LDS counter until the step's tiles run out -----------------------------------
+        auto run_tiles = [&]() __attribute__((always_inline)) {
+#pragma unroll 1
+            for (;;) {
+                int tile = 0;
+                if (lane == 0) tile = atomicAdd(tile_ctr, 1);
+                tile = __builtin_amdgcn_readfirstlane(tile);            // (not __shfl: that is an LDS crossbar round trip)
+                if (tile >= (S == 1 ? (K + 31) >> 5 : NT)) break;
+                const int tb0 = S == 1 ? tile * 32 : tile_base(tile);
+                if (S > 1 && tb0 >= K) continue;                         // (a ragged cloud: this member's tile lies beyond its end)
+                const int ia = tb0 + (lane & 15), ib = ia + 16;          // two 16-point sub-tiles, software-pipelined
+                const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
+                float bce[2], dx[2][3];
+                const float* Xf = reinterpret_cast<const float*>(X) + (lane >> 4);      // component q of the point: fc_p's B operand
+                decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
+                                        A.threshold, inv_lb, want_loss, bce, dx);
+                if (lane < 16) {
+                    if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
+                    if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
+                }
+#ifdef IFD_TRACE
+                PROF_ACC(PC_TILE0 + trace_tile);
+                ++trace_tile;
+#endif
+            }
+        };
+        if (S > 1) { PROF_T0(); run_tiles(); }
         // ---- kNN + repulsion of the points this wave owns (all waves at the same time: a VALU-only wave next to an
         //      MFMA-heavy tile wave on a SIMD is starved, f32 MFMA and VALU issue do not overlap on gfx950) -------------
-        if (wave < OWN_WAVES && use_rep) {
+        if (wave < OW && use_rep) {
             float rep_loss_a, rep_loss_b;
             KnnPt ka, kb;
             const int z = opaque_zero();
@@ -997,36 +1053,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             TRACE_STAMP(24, "s_waitcnt vmcnt(0)");            // parked state back from scratch
             uint16_t* La = cloud_lists + (size_t)(pa & (MAXK - 1)) * LIST_M;
             uint16_t* Lb = cloud_lists + (size_t)(pb & (MAXK - 1)) * LIST_M;
-            knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb,
-                      ksh, rc, rep_loss_a, rep_loss_b, cn);
+            knn_phase<S>(X, F, K, pa, pb, member * OW + wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb,
+                         cloud_lists, ka, kb, ksh, rc, rep_loss_a, rep_loss_b, cn, cv);
             const int z2 = opaque_zero();
             park_knnpt(park, z2, PARK_KNN, ka);
             park_knnpt(park, z2, PARK_KNN + 4, kb);
             if (want_loss) park[z2 + PARK_KNN + 3] = f32x4{rep_loss_a, rep_loss_b, 0.f, 0.f};
-        }
-        PROF_T0();
-        // ---- decoder tiles, pulled from an LDS counter until the step's tiles run out -----------------------------------
-#pragma unroll 1
-        for (;;) {
-            int tile = 0;
-            if (lane == 0) tile = atomicAdd(tile_ctr, 1);
-            tile = __builtin_amdgcn_readfirstlane(tile);            // (not __shfl: that is an LDS crossbar round trip)
-            if (tile >= ntiles) break;
-            const int ia = tile * 32 + (lane & 15), ib = ia + 16;    // two 16-point sub-tiles, software-pipelined
-            const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
-            float bce[2], dx[2][3];
-            const float* Xf = reinterpret_cast<const float*>(X) + (lane >> 4);      // component q of the point: fc_p's B operand
-            decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
-                                    A.threshold, inv_lb, want_loss, bce, dx);
-            if (lane < 16) {
-                if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
-                if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
+            if (S > 1) {       // this wave's neighbour terms are on their way to the other members' accumulators
+                coop_publish();
+                if (lane == 0) coop_arrive(&cv.ws->bar_knn);
             }
-#ifdef IFD_TRACE
-            PROF_ACC(PC_TILE0 + trace_tile);
-            ++trace_tile;
-#endif
         }
+        if (S == 1) { PROF_T0(); run_tiles(); }
         PROF_ACC(pc_tiles);
         // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------
         AdamState ast;
@@ -1037,9 +1075,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         unpark_knnpt(park, z3, PARK_KNN + 4, kb);
         const f32x4 rl = park[z3 + PARK_KNN + 3];
         const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
+        // split clouds: every owner wave of the cloud has sent its neighbour terms (the wait rode under the decoder tiles)
+        if (S > 1 && use_rep && wave == 0) coop_wait(&cv.ws->bar_knn, (unsigned int)(OWN_WAVES * (step + 1)));
         __syncthreads();
         PROF_ACC(pc_wait);
-        if (want_loss) {   // losses at the pre-update points of the last step
+        if (S > 1 && want_loss) {   // the last step's per-point loss terms, reduced over the whole cloud after the loop
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int pt = q ? pb : pa;
+                if (pt < K) { coop_st(&cv.ws->L[pt][0], G[pt].w); coop_st(&cv.ws->L[pt][1], q ? rl.y : rl.x); }
+            }
+        }
+        if (S == 1 && want_loss) {   // losses at the pre-update points of the last step
             float occ = (pa < K ? G[pa].w : 0.f) + (pb < K ? G[pb].w : 0.f);
             float rep = (pa < K ? rl.x : 0.f) + (pb < K ? rl.y : 0.f);
             occ = wave_sum(occ);
@@ -1054,7 +1101,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             }
         }
         float xnew[2][3], mv2;
-        adam_phase(X, G, F, K, pa, pb, step_size, bc2, rep_scale, ast, xnew, mv2);
+        adam_phase<S>(X, G, F, K, pa, pb, step_size, bc2, rep_scale, ast, xnew, mv2, cv);
         TRACE_STAMP(28, "s_waitcnt lgkmcnt(0)");              // Adam update done, X written
 #pragma unroll
         for (int q = 0; q < 2; ++q) {        // sampling coordinates of the moved points, for the next step's decoder tiles
@@ -1064,8 +1111,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         TRACE_STAMP(29, "s_waitcnt lgkmcnt(0)");              // PIX written
         if (owner) store_adam(MV, tid_s, ast);
         adam_displacement(K, pa, pb, wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
-        if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
-        __syncthreads();
+        if (S == 1) {
+            if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
+            __syncthreads();
+        } else {
+            // ---- the step's exchange between the members of a split cloud ------------------------------------------------
+            const int np = (step + 1) & 1;
+            if (wave < OW && lane == 0) {      // this owner wave's certificate maxima of the next step (adam_displacement)
+                coop_st(&cv.ws->scal[member * OW + wave][0], dmaxbuf[np * MAX_WAVES + wave]);
+                coop_st(&cv.ws->scal[member * OW + wave][1], movebuf[np * MAX_WAVES + wave]);
+            }
+            if (tid == 0) __hip_atomic_store(&cv.ws->flag[member], (int)rebuild_flag[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            coop_publish();                    // positions (adam_phase), maxima, flag: complete before this member arrives
+            __syncthreads();
+            if (wave == 0) {
+                if (lane == 0) coop_arrive(&cv.ws->bar_step);
+                coop_wait(&cv.ws->bar_step, (unsigned int)(S * (step + 1)));
+            }
+            if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }
+            __syncthreads();
+            for (int i = tid_s; i < K; i += NW * 64)       // the other members' points
+                if (!coop_owns<S>(i, member)) {
+                    const float* xg = reinterpret_cast<const float*>(cv.ws->X + i);
+                    X[i] = f32x4{coop_ld(xg), coop_ld(xg + 1), coop_ld(xg + 2), 1.f};
+                }
+            if (tid_s < OWN_WAVES) {                         // ... and their maxima (own waves: slots [0, OW), nothing here)
+                const bool mine = tid_s / OW == member;
+                dmaxbuf[np * MAX_WAVES + OWN_WAVES + tid_s] = mine ? 0.f : coop_ld(&cv.ws->scal[tid_s][0]);
+                movebuf[np * MAX_WAVES + OWN_WAVES + tid_s] = mine ? 0.f : coop_ld(&cv.ws->scal[tid_s][1]);
+            }
+            if (tid_s >= 64 && tid_s < 64 + S && tid_s - 64 != member &&
+                __hip_atomic_load(&cv.ws->flag[tid_s - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                rebuild_flag[np] = 1;
+            __syncthreads();
+        }
         PROF_ACC(pc_adam);
     }
 
@@ -1074,7 +1153,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             constexpr int SLOT[CN_COUNT] = {0, 1, 2, 4, 5, 6, 7};     // rebuilds, exact scans, extra passes, ring evaluations,
             atomicAdd(counters + SLOT[tid], (unsigned long long)lcnt[tid]);   // exact-path evaluations, refreshes, lists built
         }
-        if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
+        if (tid == 0 && cloud == 0 && member == 0) counters[3] = __builtin_readcyclecounter() - t_begin;   // shader cycles of cloud 0
 #ifdef IFD_PROF
         if (tid == 0) {
             const unsigned long long cyc = __builtin_readcyclecounter() - t_begin;
@@ -1084,6 +1163,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
         if (cloud == 0 && tid < NW * PC_COUNT && (tid % PC_COUNT) < 6) atomicAdd(counters + 8 + tid % PC_COUNT, lprof[tid]);
 #endif
+    }
+    if (S > 1 && loss_out != nullptr && A.steps > 0 && member == 0) {
+        // the last step's losses: every point's terms, summed exactly like the one-workgroup kernel sums them (thread t adds
+        // points t and t + 512, a butterfly over the wave, the eight waves in order)
+        const int qa = tid < OPT_THREADS ? tid : MAXK, qb = tid < OPT_THREADS ? tid + OPT_THREADS : MAXK;
+        float occ = (qa < K ? coop_ld(&cv.ws->L[qa][0]) : 0.f) + (qb < K ? coop_ld(&cv.ws->L[qb][0]) : 0.f);
+        float rep = (qa < K ? coop_ld(&cv.ws->L[qa][1]) : 0.f) + (qb < K ? coop_ld(&cv.ws->L[qb][1]) : 0.f);
+        occ = wave_sum(occ);
+        rep = wave_sum(rep);
+        if (lane == 0) { scratch[wave] = occ; scratch[MAX_WAVES + wave] = rep; }
+        __syncthreads();
+        if (tid == 0) {
+            float so = 0.f, sr = 0.f;
+            for (int w = 0; w < NW; ++w) { so += scratch[w]; sr += scratch[MAX_WAVES + w]; }
+            loss_out[2 * cloud + 0] = so;
+            loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
+        }
+        __syncthreads();
     }
     if (A.normalize) normalize_in_lds(X, K, scratch);
     AdamState ast;
@@ -1419,10 +1516,19 @@ constexpr size_t NRM_LDS = MAXK * 16 + 64;
 static_assert(OPT_LDS <= 160 * 1024, "LDS budget");
 
 size_t knn_list_bytes(int B) { return (size_t)B * MAXK * LIST_M * sizeof(uint16_t); }
+// the exchange blocks of split clouds (at most one partial round of them per launch) sit behind the lists
+constexpr int COOP_MAX_CLOUDS = 512;
+size_t optimize_ws_bytes(int B) { return knn_list_bytes(B) + COOP_MAX_CLOUDS * sizeof(CoopWs); }
 
 hipError_t configure_optimize_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(optimize_kernel<8, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)OPT_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
@@ -1438,13 +1544,55 @@ hipError_t configure_optimize_kernels() {
     return e;
 }
 
-hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
-                           float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
-                           unsigned long long* counters, const float* adam_tab, int B, int K, const OptArgs& a,
-                           hipStream_t s) {
-    hipLaunchKernelGGL((optimize_kernel<8>), dim3(B), dim3(512), OPT_LDS, s, dec_img, planes, p, m, v, loss,
-                       loss_batch_per_cloud, knn_lists, counters, adam_tab, K, a);
+// One launch of `n` clouds starting at cloud `c0`, S workgroups per cloud.
+template <int S>
+static hipError_t launch_part(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
+                              const int32_t* lb, uint16_t* knn_lists, unsigned long long* counters, const float* adam_tab,
+                              int c0, int n, int K, const OptArgs& a, CoopWs* coop, hipStream_t s) {
+    const size_t o3 = (size_t)c0 * K * 3;
+    const int grid = S == 1 ? n : ((n + 7) / 8) * 8 * S;       // (split clouds: members 8 workgroups apart, see the kernel)
+    if (S > 1) {
+        hipError_t e = hipMemsetAsync(coop, 0, (size_t)n * sizeof(CoopWs), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((optimize_kernel<8, S>), dim3(grid), dim3(512), OPT_LDS, s, dec_img,
+                       planes + (a.planes_shared ? 0 : (size_t)c0 * CLOUD_PLANE_FLOATS), p + o3, m ? m + o3 : nullptr,
+                       v ? v + o3 : nullptr, loss ? loss + 2 * (size_t)c0 : nullptr, lb ? lb + c0 : nullptr,
+                       knn_lists + (size_t)c0 * MAXK * LIST_M, counters, adam_tab, K, a, coop, n);
     return hipGetLastError();
+}
+
+// The persistent optimiser over B clouds.  One workgroup fills one CU (154 KB of LDS, 8 waves of 256 VGPRs), so clouds run
+// in rounds of n_cu.  split = 1: one workgroup per cloud throughout.  split = 0 (default): whole rounds likewise, but the
+// clouds of the last, partial round are split over 4 CUs each (up to n_cu / 4 clouds: 0.41 of a round, measured) or 2 (up
+// to n_cu / 2: 0.60 of a round) - a launch with fewer clouds than CUs, e.g. one GPU's shard of a file spread over 8 GPUs,
+// otherwise costs a full round.  split = 2 / 4:
+// every cloud split that way (validation: the results are bit-identical).  ws: neighbour lists of the B clouds, then the
+// exchange blocks (optimize_ws_bytes).
+hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v,
+                           float* loss, const int32_t* loss_batch_per_cloud, void* ws,
+                           unsigned long long* counters, const float* adam_tab, int B, int K, const OptArgs& a,
+                           int split, int n_cu, hipStream_t s) {
+    uint16_t* knn_lists = static_cast<uint16_t*>(ws);
+    CoopWs* coop = reinterpret_cast<CoopWs*>(static_cast<char*>(ws) + knn_list_bytes(B));
+    n_cu = max(8, min(n_cu, COOP_MAX_CLOUDS));
+    hipError_t e = hipSuccess;
+#define IFD_PART(S_, c0_, n_) \
+    launch_part<S_>(dec_img, planes, p, m, v, loss, loss_batch_per_cloud, knn_lists, counters, adam_tab, c0_, n_, K, a, coop, s)
+    if (split == 2 || split == 4) {                  // every cloud split; all workgroups of a launch must be resident
+        const int per = n_cu / split;
+        for (int c0 = 0; c0 < B && e == hipSuccess; c0 += per)
+            e = split == 2 ? IFD_PART(2, c0, min(per, B - c0)) : IFD_PART(4, c0, min(per, B - c0));
+        return e;
+    }
+    if (split == 1 || K < 256) return IFD_PART(1, 0, B);      // (tiny clouds: nothing to share out)
+    const int full = (B / n_cu) * n_cu, rest = B - full;
+    if (full > 0) e = IFD_PART(1, 0, full);
+    if (e != hipSuccess || rest == 0) return e;
+    if (4 * rest <= n_cu) return IFD_PART(4, full, rest);
+    if (2 * rest <= n_cu) return IFD_PART(2, full, rest);
+    return IFD_PART(1, full, rest);      // (more than half a round: two split launches take as long as the one round)
+#undef IFD_PART
 }
 
 // Bias corrections of torch.optim.Adam for steps t0 + 1 ... t0 + steps (torch/optim/adam.py _single_tensor_adam:

@@ -17,6 +17,9 @@ from . import _lib
 from ._lib import IfdConfig, IfdMeshParams, IfdOptParams, IfdPrepParams
 
 PLANE_ORDER = ("xz", "xy", "yz")
+# measurement hook: IFD_SPLIT=1|2|4 overrides the automatic choice of ifd_opt_params.split (results do not depend on it)
+import os as _os
+_ENV_SPLIT = int(_os.environ.get("IFD_SPLIT", "0"))
 
 
 class IfdError(RuntimeError):
@@ -195,12 +198,14 @@ class Restorer:
                         lr: float = 1e-3, loss_batch=None, normalize: bool = True,
                         state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
                         return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
-                        knn_scan_every_step: bool = False, printing: bool = False):
+                        knn_scan_every_step: bool = False, printing: bool = False, split: int = 0,
+                        planes_shared: bool = False):
         """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
         is given.  ``loss_batch`` is the reference batch size whose 1/B factor scales both losses
         (default: the number of clouds passed in); an int, or an int32 tensor [B] with one value per cloud.  ``state=(m, v, t0)`` resumes / teacher-forces.
+        ``split``: CUs per cloud (ifd_opt_params.split: 0 automatic, 1 / 2 / 4 forced; same results).
         Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
         is left to the caller.
         """
@@ -226,7 +231,7 @@ class Restorer:
             loss_batch = B
         prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
                            float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12,
-                           int(bool(knn_scan_every_step)))
+                           int(bool(knn_scan_every_step)), int(split or _ENV_SPLIT), int(bool(planes_shared)))
         with torch.cuda.device(self.device):
             self._check(self._fn_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
                                               self._ptr(lb_arr), self._ptr(m), self._ptr(v), self._ptr(loss),

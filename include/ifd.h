@@ -178,6 +178,13 @@ typedef struct ifd_opt_params {
     float   rep_eps;      /* 1e-12 */
     int32_t knn_scan_every_step; /* validation only: !=0 disables the certified neighbour lists and runs the
                                     exact brute-force 5-NN scan at every step (same results, slower) */
+    int32_t split;        /* workgroups (CUs) per cloud in the persistent kernel (ifd_optimize, K <= 1024).  0 = automatic:
+                             one per cloud in whole rounds of one cloud per CU, and the clouds of the last partial round
+                             split over 2 or 4 CUs each when that fills the GPU (fewer clouds than CUs, e.g. one GPU's shard
+                             of a file spread over 8 GPUs, would otherwise cost a whole round); 1 = never split; 2 / 4 =
+                             every cloud split (validation).  The results do not depend on it, bit for bit. */
+    int32_t planes_shared;/* measurement only: != 0 makes every cloud read the planes of cloud 0 (the tap gathers then hit in
+                             L2: scripts/ab_planes.py prices the gather traffic this way) */
 } ifd_opt_params;
 
 /* optimize_points(opt_points, z, c, rep_weight, iterations) (ConvONet/opt_defense.py:182-239).

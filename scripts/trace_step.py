@@ -14,7 +14,7 @@ x = torch.from_numpy(bench.synth_clouds(n)).cuda()
 prep = r.prepare(x, r.sor(x), seed=1234)
 planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
 lb = torch.full((n,), 192, dtype=torch.int32, device="cuda")
-r.optimize_points(prep["init"], planes, rep_weight=500.0, iterations=500, loss_batch=lb)
+r.optimize_points(prep["init"], planes, rep_weight=500.0, iterations=500, loss_batch=lb, split=int(os.environ.get("IFD_SPLIT", "0")))
 tr = r.wave_trace()
 t0 = min(w[7] for w in tr if w[7])
 names = ["build", "eval", "rep", "tiles_end", "barrier1", "adam", "T", "start"]

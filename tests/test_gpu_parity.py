@@ -222,6 +222,63 @@ def test_certified_neighbour_lists_equal_exact_scan(restorer, golden, oracle_wei
         assert ev < 151 and c["knn_brute_scans"] <= 8 * 4 * 3, c     # lists must actually be reused across steps
 
 
+def test_split_clouds_are_bit_identical_to_one_workgroup_per_cloud(restorer, golden, oracle_weights):
+    """Cooperative mode (ifd_opt_params.split): 2 or 4 workgroups - CUs - per cloud, used for the clouds of a partial round
+    (a launch with fewer clouds than CUs: one GPU's shard of a file spread over 8 GPUs).  Every member owns a quarter / half
+    of the points; neighbour terms cross CUs as integer atomics, positions and certificate maxima through global memory.
+    Points, both Adam moments and the reported losses must equal the one-workgroup kernel's bit for bit - full and ragged
+    clouds, certified lists and the exact scan, with and without the final normalisation, and resumed from a state."""
+    from oracle import convonet_oracle as O
+    import ifdefense_amd as I
+    proc = [golden["proc_pad"][b, :golden["proc_len"][b]] for b in range(4)]
+    sel = torch.from_numpy(np.stack([proc[b][golden["sel_idx"][b]] for b in range(4)]))
+    planes4 = I.planes_to_channel_last(O.encode_inputs(oracle_weights, sel)).cuda()
+    init = torch.from_numpy(golden["init_points"]).cuda()
+
+    def same(a, b):
+        return (torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[1][1], b[1][1]) and
+                torch.equal(a[2], b[2]))
+
+    for K, steps in ((1024, 120), (777, 60), (300, 60)):
+        for kw in (dict(normalize=True), dict(normalize=False, knn_scan_every_step=True)):
+            run = lambda split, st=None, n=steps: restorer.optimize_points(
+                init[:, :K].contiguous(), planes4, rep_weight=500.0, steps=n, loss_batch=192, return_state=True,
+                return_loss=True, split=split, state=st, **kw)
+            ref = run(1)
+            for split in (2, 4, 0):
+                assert same(run(split), ref), (K, kw, split)
+        # resume: 20 steps, then 7 more from the returned state (teacher-forcing path of the split kernel)
+        first = restorer.optimize_points(init[:, :K].contiguous(), planes4, rep_weight=500.0, steps=20, loss_batch=192,
+                                         normalize=False, return_state=True, split=1)
+        a = restorer.optimize_points(first[0], planes4, rep_weight=500.0, steps=7, loss_batch=192, normalize=False,
+                                     state=first[1], return_state=True, return_loss=True, split=1)
+        b = restorer.optimize_points(first[0], planes4, rep_weight=500.0, steps=7, loss_batch=192, normalize=False,
+                                     state=first[1], return_state=True, return_loss=True, split=4)
+        assert same(a, b), K
+    # rep_weight 0 (no exchange of neighbour terms at all) and tiny clouds (never split)
+    for K, rw in ((1024, 0.0), (100, 500.0)):
+        a = restorer.optimize_points(init[:, :K].contiguous(), planes4, rep_weight=rw, steps=15, split=1)
+        for split in (2, 4):
+            assert torch.equal(restorer.optimize_points(init[:, :K].contiguous(), planes4, rep_weight=rw, steps=15, split=split), a)
+
+
+def test_automatic_split_of_a_partial_round(restorer):
+    """More clouds than CUs, not a multiple: whole rounds run one workgroup per cloud, the remainder split over 4 (up to
+    a quarter of the CUs) or 2 CUs per cloud - same file, bit for bit, as with splitting disabled."""
+    import bench
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for extra in (n_cu // 8 + 3, n_cu // 2 - 5):                 # a remainder that takes S = 4, one that takes S = 2
+        n = n_cu + extra
+        x = torch.from_numpy(bench.synth_clouds(n)).cuda()
+        prep = restorer.prepare(x, restorer.sor(x), seed=5)
+        planes = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        lb = torch.full((n,), 192, dtype=torch.int32, device="cuda")
+        a = restorer.optimize_points(prep["init"], planes, rep_weight=500.0, steps=25, loss_batch=lb, split=1, return_loss=True)
+        b = restorer.optimize_points(prep["init"], planes, rep_weight=500.0, steps=25, loss_batch=lb, split=0, return_loss=True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), extra
+        assert bool(torch.isfinite(b[0]).all())
+
+
 def test_rep_weight_zero_and_small_k(restorer, golden, planes2, oracle_weights):
     from oracle import convonet_oracle as O
     init = torch.from_numpy(golden["init_points"][:2, :100]).clone()
