@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)      # ~1 s per step; the first timed pass has nothing to hide its
     ap.add_argument("--warmup", type=int, default=2)      # pre-processing under, so short runs read ~1.5 % low
     ap.add_argument("--clouds", type=int, default=N_CLOUDS, help="clouds per GPU per step (default: MN40 test size)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every rank restores its own --clouds clouds; strong: ONE array of --clouds clouds is "
+                         "sharded over the ranks (BASELINE configs #3 / #5: one .npz over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="serial passes (no second stream for the next pass's pre-processing)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements (reference-style unfused "
@@ -277,7 +280,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    total = a.clouds * world
+    total = a.clouds * world if a.scaling == "weak" else a.clouds
     lo, hi, per = D.shard_range(total, rank, world)
     my_clouds = synth_clouds(hi - lo, start=lo)                         # every rank synthesises only its own shard
     x = torch.from_numpy(my_clouds).to(dev)                             # resident in HBM before timing
@@ -362,11 +365,11 @@ def main():
             "metric": "restored clouds/sec (1024-pt ModelNet40, %s 500 iters)" % ("ONet-Opt" if onet else "ConvONet-Opt"),
             "value": round(total * a.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s on ModelNet40-test-like .npz: %d clouds/GPU x 1024 pts, --iterations=500 "
                                    "(501 Adam steps), SOR on, batch_size 192; SOR+preprocess+encode+init+optimise+"
-                                   "normalise+gather" % ("ONet-Opt" if onet else "ConvONet-Opt", a.clouds),
-                       "clouds_per_gpu": a.clouds, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
+                                   "normalise+gather" % ("ONet-Opt" if onet else "ConvONet-Opt", per),
+                       "clouds_per_gpu": per, "clouds_total": total, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
                        "parallelism": "shard%d+allgather" % world, "weights": "seeded random (seed 0)",
                        "driver": "passes streamed: pre-processing of pass n+1 on a second HIP stream under pass n's optimiser tail"
                                  if not a.no_overlap else "serial passes"},

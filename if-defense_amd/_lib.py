@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libifd.so")
+# IFD_LIB: another build of the same library (test hook: csrc/libifd_exact.so, the -DIFD_EXACT_REP build)
+LIB_PATH = os.environ.get("IFD_LIB") or os.path.join(HERE, "csrc", "libifd.so")
 
 IFD_OK = 0
 ABI_VERSION = 1

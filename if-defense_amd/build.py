@@ -16,6 +16,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libifd.so")
+# the same library with the optimiser kernels' repulsion terms on the IEEE sqrt / divide / expf expansions instead of the
+# 1-ulp hardware instructions (-DIFD_EXACT_REP, knn_device.h rep_point2): built next to the default one so that a GPU test
+# can hold the two against each other (tests/test_gpu_parity.py::test_exact_repulsion_build)
+LIB_EXACT = os.path.join(CSRC, "libifd_exact.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("IFD_EXTRA_FLAGS", "").split()
@@ -38,10 +42,10 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.splitext(src)[0] + ".o"
+def _compile(src: str, force: bool, extra=(), suffix="") -> str:
+    obj = os.path.splitext(src)[0] + suffix + ".o"
     if force or _stale(obj, [src] + _deps()):
-        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -60,13 +64,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = " ".join(f for f in FLAGS if not f.startswith("-I"))      # location-independent: the tree travels to the GPU box
     if not os.path.exists(STAMP) or open(STAMP).read() != flags:
         force = True
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    opt_src = os.path.join(CSRC, "optimize.hip")
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs) + 1)) as ex:
+        exact = ex.submit(_compile, opt_src, force, ("-DIFD_EXACT_REP",), "_exact")
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        exact_obj = exact.result()
+    for lib, olist in ((LIB, objs), (LIB_EXACT, [exact_obj if o == os.path.splitext(opt_src)[0] + ".o" else o for o in objs])):
+        if force or _stale(lib, olist):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + olist
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(STAMP, "w") as f:
         f.write(flags)
     if verbose:

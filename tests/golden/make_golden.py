@@ -11,8 +11,10 @@ Shims: stub modules for the mesh-only native libs and
 ``trimesh`` (imported eagerly by src/conv_onet/__init__.py), a ``torch_scatter``
 stand-in (torch-scatter 2.0.5 is not installed), and a no-op ``Tensor.cuda``.
 ``opt_defense.py`` itself is not importable (argparse + torch.load + cuda at
-import time), so its 30-line ``optimize_points`` loop is driven from here with
-the reference's ``model.decode`` / ``repulsion_loss`` / ``torch.optim.Adam``.
+import time); its driver functions (sor_process, preprocess_pc, init_points,
+optimize_points, normalize_batch_pc, defend_point_cloud) are executed FROM ITS
+SOURCE by ref_driver.py (ast: the FunctionDef nodes only) with recorded random
+draws - nothing of the driver is restated here.
 
     python tests/golden/make_golden.py
 """
@@ -108,48 +110,7 @@ def synth_clouds(rng):
     return np.stack([norm(air), norm(sphere), norm(torus), norm(box)])
 
 
-def ref_preprocess(pc, padding_scale=0.9):
-    """numpy lines of opt_defense.preprocess_pc (:122-127); the random subset is drawn by the caller."""
-    center = np.mean(pc, axis=0)
-    centered = pc - center
-    scale = (np.max(centered, axis=0) - np.min(centered, axis=0)).max()
-    return centered / scale * padding_scale
-
-
-def ref_optimize(model, init, planes, iterations, rep_weight=500.0, lr=1e-3, threshold=0.2, record=()):
-    """The loop of opt_defense.optimize_points (:198-238) around the reference model + loss."""
-    import torch.nn.functional as F
-    x = init.clone().float()
-    x.requires_grad_()
-    B, K = x.shape[:2]
-    target = torch.ones((B, K)).float() * threshold
-    opt = torch.optim.Adam([x], lr=lr)
-    snaps = {}
-    for i in range(iterations + 1):
-        occ_value = model.decode(x, planes).logits
-        occ_loss = F.binary_cross_entropy_with_logits(occ_value, target, reduction="none")
-        occ_loss = torch.mean(occ_loss) * K
-        rep_loss = torch.mean(repulsion_loss(x)) * rep_weight
-        loss = occ_loss + rep_loss
-        opt.zero_grad()
-        loss.backward()
-        if i in record:
-            st = opt.state[x]
-            snaps[i] = dict(x=x.detach().clone(), g=x.grad.detach().clone(),
-                            m=st["exp_avg"].clone() if st else torch.zeros_like(x),
-                            v=st["exp_avg_sq"].clone() if st else torch.zeros_like(x),
-                            occ=float(occ_loss), rep=float(rep_loss))
-        opt.step()
-        if i in record:
-            snaps[i]["x_next"] = x.detach().clone()
-    return x.detach(), snaps
-
-
-def ref_normalize(points):
-    centroid = torch.mean(points, dim=1)
-    points = points - centroid[:, None, :]
-    dist = torch.sum(points ** 2, dim=2) ** 0.5
-    return points / torch.max(dist, dim=1)[0][:, None, None]
+import ref_driver as RD                                        # noqa: E402  (the reference's own driver functions)
 
 
 def main():
@@ -179,13 +140,21 @@ def main():
     print("SOR kept:", keep_mask.sum(1))
 
     # G6: preprocess (+ recorded random draws: 600-subset, 1024 init indices, N(0,1) noise)
-    proc, sel_idx, init_idx = [], [], []
-    for b in range(4):
-        pts = ref_preprocess(raw[b][keep_mask[b]])
-        proc.append(pts.astype(np.float32))
-        sel_idx.append(rng.choice(len(pts), 600, replace=False))
-        init_idx.append(rng.integers(0, len(pts), 1024))
+    # the draws come from the fixture's generator; the reference's functions consume them through ref_driver's proxies
+    lens0 = keep_mask.sum(1)
+    sel_idx, init_idx = [], []
+    for b in range(4):                                             # (draw order of the round-1 fixtures)
+        sel_idx.append(rng.choice(int(lens0[b]), 600, replace=False))
+        init_idx.append(rng.integers(0, int(lens0[b]), 1024))
     noise = rng.standard_normal((4, 1024, 3)).astype(np.float32)
+    draws = RD.Draws(choice=sel_idx, randint=[torch.from_numpy(i).long() for i in init_idx], randn=[torch.from_numpy(noise)])
+    ns = RD.load(model, RD.default_args(), draws)
+    sor_list = ns["sor_process"](raw)                              # the reference's sor_process (:86-111)
+    for b in range(4):
+        assert np.array_equal(sor_list[b], raw[b][keep_mask[b]])
+    pre = [ns["preprocess_pc"](sor_list[b], num_points=600, padding_scale=0.9) for b in range(4)]   # (:114-146)
+    proc = [pre[b][0][0].numpy() for b in range(4)]
+    sel_ref = torch.cat([pre[b][1] for b in range(4)], dim=0)
     lens = np.array([len(p) for p in proc])
     proc_pad = np.zeros((4, 1024, 3), np.float32)
     for b in range(4):
@@ -193,6 +162,7 @@ def main():
     out.update(proc_len=lens, proc_pad=proc_pad, sel_idx=np.stack(sel_idx), init_idx=np.stack(init_idx),
                noise=noise)
     sel = torch.from_numpy(np.stack([proc[b][sel_idx[b]] for b in range(4)]))      # [4,600,3]
+    assert torch.equal(sel, sel_ref)                              # preprocess_pc's own subset = the recorded draw applied
 
     # G1: encoder stages (reference LocalPoolPointnet)
     enc = model.encoder
@@ -204,14 +174,17 @@ def main():
         index = {pl: coordinate2index(coord[pl], 64) for pl in coord}
         net = enc.blocks[0](enc.fc_pos(sel))
         stage0 = net.clone()
+        pooled_stages = []
         for blk in enc.blocks[1:]:
-            pooled = enc.pool_local(coord, index, net)
+            pooled = enc.pool_local(coord, index, net)             # pointnet.py:104-122
+            pooled_stages.append(pooled[:2].clone())
             net = blk(torch.cat([net, pooled], dim=2))
         c_pts = enc.fc_c(net)
         fea = c_pts.new_zeros(4, 32, 64 * 64)
         pre_xz = ts.scatter_mean(c_pts.permute(0, 2, 1), index["xz"], out=fea).reshape(4, 32, 64, 64)
     out["enc_index"] = np.stack([index[pl][:, 0].numpy() for pl in ("xz", "xy", "yz")], 1).astype(np.int32)
     out["enc_stage0"] = stage0[:2].numpy()
+    out["enc_pooled"] = torch.stack(pooled_stages, 1).numpy()     # G1: [2,4,600,32] pool_local outputs of the four stages
     out["enc_c"] = c_pts.numpy()
     out["enc_pre_xz0"] = pre_xz[0].numpy()
     out["planes01"] = np.stack([planes[pl][:2].numpy() for pl in ("xz", "xy", "yz")], 1)   # [2,3,32,64,64]
@@ -219,8 +192,8 @@ def main():
                                     for b in range(4) for pl in ("xz", "xy", "yz")]).reshape(4, 3, 2)
 
     # init points (reference init_points lines :169-178 with the recorded draws)
-    pts0 = torch.stack([torch.from_numpy(proc[b])[torch.from_numpy(init_idx[b])] for b in range(4)])
-    pts0 = torch.clamp(pts0 + torch.from_numpy(noise) * 0.01, min=-0.45, max=0.45)
+    pts0 = ns["init_points"]([pre[b][0][0] for b in range(4)])   # the reference's init_points (:149-179), recorded draws
+    assert not draws.choice and not draws.randint and not draws.randn      # every recorded draw was consumed
     out["init_points"] = pts0.numpy()
 
     # G2: decoder logits + d(sum logits)/dp on clouds 0,1
@@ -239,7 +212,8 @@ def main():
 
     # G3/G4/G7: trajectory snapshots incl. Adam state for teacher-forced single steps (B=2)
     rec = (0, 1, 9, 49)
-    xT, snaps = ref_optimize(model, pts0[:2], planes2, iterations=50, record=rec)
+    _, snaps = RD.run_optimize(ns, pts0[:2], planes2, iterations=50, record=rec)   # the reference's optimize_points (:182-239)
+    xT = snaps["final_unnormalised"]
     for i in rec:
         s = snaps[i]
         for k in ("x", "g", "m", "v", "x_next"):
@@ -248,12 +222,19 @@ def main():
     out["traj_final51"] = xT.numpy()
 
     # G8: end to end on all 4 clouds, iterations=20 (21 steps), B=4, normalised output
-    x20, _ = ref_optimize(model, pts0, planes, iterations=20)
-    out["e2e20_out"] = ref_normalize(x20).numpy()
+    e2e, _ = RD.run_optimize(ns, pts0, planes, iterations=20)
+    out["e2e20_out"] = e2e
+    # ... and the same through the reference's whole driver, defend_point_cloud (:255-314: sor_process, preprocess_pc,
+    # encode_inputs, init_points, optimize_points per batch), fed the same recorded draws
+    draws2 = RD.Draws(choice=sel_idx, randint=[torch.from_numpy(i).long() for i in init_idx], randn=[torch.from_numpy(noise)])
+    ns2 = RD.load(model, RD.default_args(iterations=20), draws2)
+    full = ns2["defend_point_cloud"](raw)
+    assert np.array_equal(full, e2e), "defend_point_cloud != its parts"
 
     # self-divergence floor of the reference under a 1-ulp perturbation (context for P2/P3)
     pert = pts0[:2] * (1 + 1e-7)
-    xp, _ = ref_optimize(model, pert, planes2, iterations=50)
+    _, sp = RD.run_optimize(ns, pert, planes2, iterations=50)
+    xp = sp["final_unnormalised"]
     d = (xp - xT).norm(dim=-1)
     out["selfdiv51"] = np.array([float(d.max()), float(d.mean()), float((d > 1e-3).float().mean())])
     print("self-divergence @51 steps: max %.3e mean %.3e frac>1e-3 %.3f" % tuple(out["selfdiv51"]))

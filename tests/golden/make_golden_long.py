@@ -23,7 +23,8 @@ def main():
     planes2 = {pl: torch.from_numpy(g["planes01"][:, i]) for i, pl in enumerate(("xz", "xy", "yz"))}
     init = torch.from_numpy(g["init_points"][:2])
     rec = (99, 499)
-    _, snaps = MG.ref_optimize(model, init, planes2, iterations=499, record=rec)
+    ns = MG.RD.load(model, MG.RD.default_args())
+    _, snaps = MG.RD.run_optimize(ns, init, planes2, iterations=499, record=rec)     # the reference's own optimize_points
     out = {}
     for i in rec:
         for k in ("x", "g", "m", "v", "x_next"):

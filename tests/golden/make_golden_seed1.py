@@ -31,7 +31,8 @@ def main():
         planes = model.encode_inputs(sel)
     init = torch.from_numpy(g["init_points"])                       # [4,1024,3]
     rec = (0, 1, 9, 49, 99)
-    _, snaps = MG.ref_optimize(model, init, planes, iterations=99, record=rec)
+    ns = MG.RD.load(model, MG.RD.default_args())
+    _, snaps = MG.RD.run_optimize(ns, init, planes, iterations=99, record=rec)       # the reference's own optimize_points
     out = {"planes": np.stack([planes[pl].numpy() for pl in ("xz", "xy", "yz")], 1)}      # [4,3,32,64,64]
     for i in rec:
         for k in ("x", "g", "m", "v", "x_next"):

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Fixtures of the CONVERGED-SURFACE regime: the reference's modules and the reference's own driver functions
+(ref_driver.py: executed from ConvONet/opt_defense.py's source) on the trained-like checkpoint
+tests/golden/trained_like_f16.npz (train_trained_like.py), EIGHT clouds - one of every bench shape family + a second
+sphere - so B = 8 in the 1/B loss factor.
+
+Every other fixture uses seeded random weights, whose occupancy field never crosses the configured iso-value; here the
+field has a closed surface at logit(0.2) and the optimised points converge onto it.  Recorded: the reference's SOR output
+sizes, the draws its preprocess_pc / init_points made (seeded here, then replayed by the tests), the 600-point encoder
+inputs, the planes its encoder produced ROUNDED TO FLOAT16 (6 MB instead of 12; the reference's decode / optimize_points
+then ran on exactly these rounded planes, so decoder and optimiser parity is pinned on them bit for bit - the encoder
+has its own fixtures), decoder logits and input gradient at the initial points (G2), (x, grad, exp_avg, exp_avg_sq,
+x_next, losses) at steps 0, 9, 99 (G4 / G7) and the function's normalised return value after 100 steps.
+Writes tests/golden/convonet_golden_trained.npz.  Build container only.
+
+    python tests/golden/make_golden_trained.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG  # noqa: E402  (registers the shims, imports the reference modules)
+
+sys.path.insert(0, MG.ROOT)
+import bench  # noqa: E402  (synth_clouds: the bench's shape families)
+
+RD = MG.RD
+PL = ("xz", "xy", "yz")
+
+
+def load_trained_like():
+    z = np.load(os.path.join(HERE, "trained_like_f16.npz"))
+    return {k: torch.from_numpy(z[k].astype(np.float32)) for k in z.files}
+
+
+def main():
+    model = MG.build_reference_model()                 # architecture; the weights are replaced below
+    print("load trained-like:", model.load_state_dict(load_trained_like(), strict=True))
+    raw = bench.synth_clouds(8, seed=77)               # kinds 0..6 + a second sphere
+    np.random.seed(7)
+    torch.manual_seed(7)
+    draws = RD.Draws()                                 # nothing recorded yet: the proxies draw and log
+    ns = RD.load(model, RD.default_args(), draws)
+    sor_list = ns["sor_process"](raw)
+    pre = [ns["preprocess_pc"](p, num_points=600, padding_scale=0.9) for p in sor_list]
+    sel = torch.cat([p[1] for p in pre], dim=0)
+    with torch.no_grad():
+        planes = model.encode_inputs(sel)
+    planes = {pl: planes[pl].half().float() for pl in PL}           # the fixture's planes ARE the rounded ones
+    init = ns["init_points"]([p[0][0] for p in pre])
+    out = {"raw": raw, "sor_len": np.array([len(p) for p in sor_list], np.int32),
+           "sel_idx": np.stack(draws.log["choice"]).astype(np.int32),
+           "init_idx": np.stack([t.numpy() for t in draws.log["randint"]]).astype(np.int32),
+           "noise": draws.log["randn"][0].numpy(), "sel": sel.numpy(),
+           "planes_f16": np.stack([planes[pl].numpy() for pl in PL], 1).astype(np.float16),      # [8,3,32,64,64]
+           "init_points": init.numpy()}
+    p = init.clone().requires_grad_()
+    logits = model.decode(p, planes).logits
+    logits.sum().backward()
+    out["dec_logits"], out["dec_dlogit_dp"] = logits.detach().numpy(), p.grad.numpy().copy()
+    rec = (0, 9, 99)
+    final, snaps = RD.run_optimize(ns, init, planes, iterations=99, record=rec)
+    for i in rec:
+        for k in ("x", "g", "m", "v", "x_next"):
+            out[f"traj{i}_{k}"] = snaps[i][k].numpy()
+        out[f"traj{i}_loss"] = np.array([snaps[i]["occ"], snaps[i]["rep"]], np.float64)
+    out["out100_normalised"] = final
+    # how converged: occupancy probability of the points before / after (the iso-value is 0.2)
+    with torch.no_grad():
+        s0 = torch.sigmoid(model.decode(init, planes).logits)
+        s1 = torch.sigmoid(model.decode(snaps["final_unnormalised"], planes).logits)
+    out["occ_prob_init_final"] = np.stack([s0.numpy(), s1.numpy()])
+    print("occupancy probability at the points: init mean %.3f (|p - 0.2| %.3f) -> after 100 steps mean %.3f (|p - 0.2| %.3f)" %
+          (float(s0.mean()), float((s0 - 0.2).abs().mean()), float(s1.mean()), float((s1 - 0.2).abs().mean())))
+    lg = model.decode((torch.rand(8, 20000, 3) - 0.5) * 1.1, planes).logits
+    print("field: fraction of the cube above logit(0.2): %.3f, logit range %.1f ... %.1f" %
+          (float((torch.sigmoid(lg) > 0.2).float().mean()), float(lg.min()), float(lg.max())))
+    path = os.path.join(HERE, "convonet_golden_trained.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -174,7 +174,11 @@ def test_end_to_end_21_steps_normalised(restorer, golden, oracle_weights):
     out = restorer.optimize_points(torch.from_numpy(golden["init_points"]), planes4, rep_weight=500.0, iterations=20)
     out = out.cpu().numpy()
     d = np.linalg.norm(out - golden["e2e20_out"], axis=-1)
-    assert np.median(d) < 1e-4 and (d > 1e-2).mean() < 0.01, (np.median(d), d.max())
+    print("e2e 21 steps + normalisation: median %.2e max %.2e, points > 1e-3: %d, > 1e-2: %d of %d" %
+          (np.median(d), d.max(), (d > 1e-3).sum(), (d > 1e-2).sum(), d.size))
+    # measured (round 3): median 5.0e-7, max 5.5e-4, no point beyond 1e-3 - asserted at 2x, so that a regression of a few
+    # flipped neighbours fails (the north-star bound, 1e-3 per point, holds for every point here)
+    assert np.median(d) < 1e-6 and d.max() < 1.1e-3 and (d > 1e-3).sum() == 0, (np.median(d), d.max())
     np.testing.assert_allclose(np.linalg.norm(out, axis=-1).max(axis=1), 1.0, rtol=1e-6)
     assert np.abs(out.mean(axis=1)).max() < 1e-3
 
@@ -307,7 +311,7 @@ def test_large_clouds_more_than_1024_points(restorer, golden, planes2, oracle_we
         np.testing.assert_allclose(loss.cpu().numpy(), O.repulsion_loss(init, ref_idx).numpy(), rtol=2e-5)
         same = (np.sort(knn.cpu().numpy(), -1) == np.sort(ref_idx.numpy(), -1)).all(-1)
         print("large K=%d: kNN sets equal for %d of %d points" % (K, same.sum(), same.size))
-        assert same.mean() > 0.999, K             # the expanded-form distances of the reference reorder near-ties
+        assert (~same).sum() <= 2, K              # measured: all equal (the reference's expanded-form distances may reorder a near-tie)
         # P1: single steps from the oracle's own trajectory
         x, m, v = init.clone(), torch.zeros_like(init), torch.zeros_like(init)
         for t in range(1, 7):
@@ -337,7 +341,8 @@ def test_large_clouds_more_than_1024_points(restorer, golden, planes2, oracle_we
         print("large K=%d free run of 6 steps + normalisation: %d of %d points off by > 2e-5 (max %.1e)" % (K, (err > 2e-5).sum(), err.size, err.max()))
         # (a near-tie neighbour choice moves a point by ~lr per step; these clouds are crowded on purpose - up to three
         # points per source point - and the measured counts are 0 / 4 / 17 of 2050 / 4096 / 6000)
-        assert (err > 2e-5).mean() < 1e-2 and err.max() < 1e-2, K
+        max_off, max_err = {1025: (2, 1e-5), 2048: (8, 1e-3), 3000: (34, 8e-3)}[K]      # 2x the measured 0 / 4 / 17, 2.2e-6 / 4.8e-4 / 3.6e-3
+        assert (err > 2e-5).sum() <= max_off and err.max() < max_err, (K, int((err > 2e-5).sum()), float(err.max()))
         assert abs(float(got.norm(dim=-1).max()) - 1.0) < 1e-5 and torch.isfinite(lv).all()
 
 
@@ -523,7 +528,8 @@ def test_config3_knn_attack_like_clouds(restorer, golden, oracle_weights):
     # relative, which is the rounding noise of the reference's own |a|^2 + |b|^2 - 2ab distance: a flipped
     # neighbour moves that one point - allow 1 point in 1000, bound the rest
     print("config #3, 10 steps: max %.2e, median %.2e, points > 1e-3: %d of %d" % (d.max(), np.median(d), (d > 1e-3).sum(), d.size))
-    assert (d > 1e-3).mean() < 1e-3 and np.median(d) < 1e-5 and d.max() < 1e-2, (d.max(), np.median(d))
+    # measured (round 3): 1 of 4096 points beyond 1e-3 (1.26e-3), median 3.2e-7
+    assert (d > 1e-3).sum() <= 2 and np.median(d) < 1e-6 and d.max() < 2.6e-3, (d.max(), np.median(d), int((d > 1e-3).sum()))
     # 150 steps on the clustered clouds: lists + individual refreshes == exact scan, bit for bit
     planes = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
     a = restorer.optimize_points(prep["init"], planes, rep_weight=500.0, iterations=150, normalize=False)
@@ -551,7 +557,11 @@ def test_config5_sparse_inputs(restorer, golden, oracle_weights):
             # one point by ~lr per step.  Count them, bound everything else.
             print("config #5 K=%d sor=%s: max %.2e median %.2e, points > 1e-3: %d of %d" %
                   (clouds.shape[1], sor, d.max(), np.median(d), (d > 1e-3).sum(), d.size))
-            assert (d > 1e-3).mean() < 5e-3 and np.median(d) < 1e-5 and d.max() < 5e-2, (clouds.shape, sor, d.max())
+            # measured (round 3): K = 824: 0 points beyond 1e-3 (max 2.9e-4 / 1.1e-4); K = 256: 13 (max 1.6e-2) with SOR,
+            # 2 (max 1.9e-3) without - asserted at 2x the measured values
+            max_off, max_d = {(824, True): (0, 6e-4), (824, False): (0, 3e-4), (256, True): (26, 3.2e-2), (256, False): (4, 4e-3)}[
+                (clouds.shape[1], sor)]
+            assert (d > 1e-3).sum() <= max_off and np.median(d) < 1e-6 and d.max() < max_d, (clouds.shape, sor, d.max(), int((d > 1e-3).sum()))
 
 
 def test_unet_matches_reference_and_is_batch_invariant(restorer, golden):
@@ -1204,3 +1214,63 @@ def test_optimise_point_count_sweep(restorer, golden, planes2, oracle_weights, k
     ref = O.optimize_points(oracle_weights, init, planes2, rep_weight=500.0, iterations=5, normalize=True)
     got = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=5, normalize=True)
     assert np.linalg.norm(got.cpu().numpy() - ref.numpy(), axis=-1).max() < 1e-4
+
+
+_EXACT_SCRIPT = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+import ifdefense_amd as I
+from ifdefense_amd import _lib
+from oracle import convonet_oracle as O
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "convonet_golden.npz"))
+planes = {pl: torch.from_numpy(g["planes01"][:, i]) for i, pl in enumerate(("xz", "xy", "yz"))}
+r = I.Restorer(I.weights.pack_state_dict(O.make_random_weights(0)), device="cuda:0")
+out = {"lib": np.array(os.path.basename(_lib.LIB_PATH))}
+for i in (0, 1, 9, 49):
+    x, m, v = (torch.from_numpy(g["traj%d_%s" % (i, k)]) for k in ("x", "m", "v"))
+    x1, (m1, v1, _) = r.optimize_points(x, planes, rep_weight=500.0, steps=1, normalize=False, state=(m, v, i),
+                                        return_state=True, split=1)
+    out["x1_%d" % i] = x1.cpu().numpy()
+    out["g_%d" % i] = (m1.cpu().numpy() - 0.9 * m.numpy()) / 0.1        # the kernel's gradient, from Adam's first moment
+free = r.optimize_points(torch.from_numpy(g["init_points"][:2]), planes, rep_weight=500.0, iterations=9, normalize=False)
+out["free10"] = free.cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_exact_repulsion_build(tmp_path, golden):
+    """The default build takes sqrt, 1/h, 1/d and exp of the repulsion terms from the 1-ulp hardware instructions
+    (knn_device.h rep_point2); -DIFD_EXACT_REP (csrc/libifd_exact.so, built next to libifd.so) uses the IEEE expansions the
+    reference's kernels use (defense/repulsion_loss.py:43-54).  Both builds, each in its own process: P1 from the
+    reference's states at t = 1, 2, 10, 50 with 0 coordinates off by more than 1e-6 in EITHER build, each build's gradient
+    within 5e-6 of the reference's autograd gradient, the two builds' gradients within 2e-6 of each other (of the maximum),
+    and 10 free-running steps of the two builds within 1e-5."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exact = os.path.join(root, "if-defense_amd", "csrc", "libifd_exact.so")
+    assert os.path.exists(exact), "libifd_exact.so is not built (python if-defense_amd/build.py)"
+    (tmp_path / "run.py").write_text(_EXACT_SCRIPT)
+    res = {}
+    for name, lib in (("default", ""), ("exact", exact)):
+        env = dict(os.environ, IFD_LIB=lib)
+        r = subprocess.run([sys.executable, str(tmp_path / "run.py"), root, str(tmp_path / (name + ".npz"))],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[name] = dict(np.load(tmp_path / (name + ".npz")))
+    assert str(res["exact"]["lib"]) == "libifd_exact.so" and str(res["default"]["lib"]) == "libifd.so"
+    for i in (0, 1, 9, 49):
+        g_ref, x_next = golden["traj%d_g" % i], golden["traj%d_x_next" % i]
+        gmax = np.abs(g_ref).max()
+        for name in ("default", "exact"):
+            flips = int((np.abs(res[name]["x1_%d" % i] - x_next) > 1e-6).sum())
+            gerr = np.abs(res[name]["g_%d" % i] - g_ref).max() / gmax
+            print("%-7s build, t=%d: coordinates off by > 1e-6: %d, gradient error %.2e of max" % (name, i + 1, flips, gerr))
+            assert flips == 0 and gerr < 5e-6, (name, i)
+        between = np.abs(res["default"]["g_%d" % i] - res["exact"]["g_%d" % i]).max() / gmax
+        print("default vs exact build, t=%d: gradient difference %.2e of max" % (i + 1, between))
+        assert between < 2e-6, i
+    d = np.linalg.norm(res["default"]["free10"] - res["exact"]["free10"], axis=-1)
+    print("default vs exact build, 10 free steps: max per-point L2 %.2e" % d.max())
+    assert d.max() < 1e-5
