@@ -217,6 +217,38 @@ def extras(dev):
                                               "%d of %d Adam steps timed, scaled" % (n, steps, ITERATIONS + 1)}
     except Exception as e:      # noqa: BLE001  (a side measurement must never take the headline line down)
         out["reference_style_gpu"] = {"error": str(e)[:200]}
+    try:      # the converged-surface regime: the optimiser on a TRAINED-LIKE field (tests/golden/train_trained_like.py)
+        z = np.load(os.path.join(ROOT, "tests", "golden", "trained_like_f16.npz"))
+        r = I.Restorer(I.weights.pack_state_dict({k: z[k].astype(np.float32) for k in z.files}), device=dev)
+        n = 512                                                     # two whole rounds of one cloud per CU
+        x = torch.from_numpy(synth_clouds(n)).to(dev)
+        prep = r.prepare(x, r.sor(x), seed=1234)
+        planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        lb = torch.full((n,), 192, dtype=torch.int32, device=dev)
+        r.optimize_points(prep["init"][:8], planes[:8], rep_weight=500.0, steps=2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pts = r.optimize_points(prep["init"], planes, rep_weight=500.0, iterations=ITERATIONS, loss_batch=lb, normalize=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        c = r.counters()
+        p0 = torch.sigmoid(r.decode(prep["init"], planes))
+        p1 = torch.sigmoid(r.decode(pts, planes))
+        out["trained_like"] = {
+            "value": round(n / (ms * 1e-3), 1), "unit": "clouds/s (optimiser launch only)",
+            "roofline_frac": round(FLOP_DENSE_PER_CLOUD * n / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "list_rebuilds_per_cloud": round(c["knn_rebuilds"] / 8.0 / n, 2),
+            "ring_use_fraction": round(c["knn_ring_evals"] / (8.0 * n * (ITERATIONS + 1)), 3),
+            "exact_query_fraction": round(c["knn_exact_evals"] / (8.0 * n * (ITERATIONS + 1)), 4),
+            "occupancy_prob_abs_dev_from_threshold": {"init": round(float((p0 - 0.2).abs().mean()), 4),
+                                                      "restored": round(float((p1 - 0.2).abs().mean()), 4)},
+            "what": "ifd_optimize on %d bench clouds with the trained-like checkpoint (tests/golden/trained_like_f16.npz: the "
+                    "reference model trained on analytic occupancy of the bench shapes; a field with a surface at the "
+                    "iso-value 0.2), 501 Adam steps, one workgroup per cloud" % n}
+        r.close()
+    except Exception as e:      # noqa: BLE001
+        out["trained_like"] = {"error": str(e)[:200]}
     try:      # ONet-Opt decoder variant: 256 clouds x 51 steps, scaled to 501
         r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device=dev)
         x = torch.from_numpy(synth_clouds(256)).to(dev)

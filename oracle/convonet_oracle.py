@@ -176,14 +176,18 @@ def pointnet_features(w: Weights, p: torch.Tensor, return_stages: bool = False):
     coords = {pl: normalize_coordinate(p, pl) for pl in PLANES}
     index = {pl: coordinate2index(coords[pl]) for pl in PLANES}
     stages: List[torch.Tensor] = []
+    pooled_stages: List[torch.Tensor] = []
     net = F.linear(p, w["encoder.fc_pos.weight"], w["encoder.fc_pos.bias"])
     net = resnet_block_fc(w, "encoder.blocks.0", net)
     stages.append(net)
     for i in range(1, N_BLOCKS):
-        pooled = sum(scatter_max_gather(net, index[pl], PLANE_RES ** 2) for pl in PLANES)
+        pooled = sum(scatter_max_gather(net, index[pl], PLANE_RES ** 2) for pl in PLANES)      # pool_local, pointnet.py:104-122
+        pooled_stages.append(pooled)
         net = resnet_block_fc(w, f"encoder.blocks.{i}", torch.cat([net, pooled], dim=2))
         stages.append(net)
     c = F.linear(net, w["encoder.fc_c.weight"], w["encoder.fc_c.bias"])
+    if return_stages == "pooled":
+        return c, index, stages, pooled_stages
     if return_stages:
         return c, index, stages
     return c, index

@@ -50,6 +50,11 @@ def test_encoder_pointnet(golden, oracle_weights):
     np.testing.assert_allclose(c.numpy(), golden["enc_c"], rtol=1e-4, atol=2e-6)
     pre = O.scatter_mean_plane(c, index["xz"])
     np.testing.assert_allclose(pre[0].numpy(), golden["enc_pre_xz0"], rtol=1e-4, atol=2e-6)
+    # G1: the pooled-stage tensors - pool_local's output (scatter_max over the three planes' cells, gathered back,
+    # summed; pointnet.py:104-122) at each of the four pooling stages, as the reference module produced them
+    pooled = O.pointnet_features(oracle_weights, sel, return_stages="pooled")[3]
+    for k in range(4):
+        np.testing.assert_allclose(pooled[k][:2].numpy(), golden["enc_pooled"][:, k], rtol=1e-4, atol=2e-6)
 
 
 def test_encoder_planes(golden, oracle_weights):
@@ -153,3 +158,47 @@ def test_oracle_late_teacher_forced_steps(oracle_weights, golden):
         xn, _, _ = O.adam_step(x.detach(), torch.from_numpy(gl[f"traj{t}_g"]), torch.from_numpy(gl[f"traj{t}_m"]),
                                torch.from_numpy(gl[f"traj{t}_v"]), t + 1)
         assert np.abs(xn.numpy() - gl[f"traj{t}_x_next"]).max() < 1e-6
+
+
+# ---- the trained-like fixtures (converged-surface regime; tests/golden/make_golden_trained.py) ---------------------------
+def _trained():
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "trained_like_f16.npz"))
+    w = O.to_torch({k: z[k].astype(np.float32) for k in z.files})
+    f = np.load(os.path.join(here, "convonet_golden_trained.npz"))
+    planes = {pl: torch.from_numpy(f["planes_f16"][:, i].astype(np.float32)) for i, pl in enumerate(PL)}
+    return w, f, planes
+
+
+def test_trained_like_oracle_driver_and_decoder():
+    """The oracle's driver restatements against what the reference's OWN functions (executed from opt_defense.py's source)
+    produced on the trained-like checkpoint: SOR sizes, preprocess + recorded subset, init points - bit for bit - and the
+    decoder's logits / input gradient."""
+    w, f, planes = _trained()
+    keep, _ = O.sor_keep_mask(torch.from_numpy(f["raw"]))
+    assert (keep.sum(1).numpy() == f["sor_len"]).all()
+    proc = [O.preprocess_pc(f["raw"][b][keep[b].numpy()]) for b in range(8)]
+    sel = np.stack([proc[b][f["sel_idx"][b]] for b in range(8)])
+    np.testing.assert_array_equal(sel, f["sel"])
+    init = O.init_points(proc, f["init_idx"], f["noise"])
+    np.testing.assert_array_equal(init.numpy(), f["init_points"])
+    p = init[:4].clone().requires_grad_()
+    logits = O.decode_logits(w, p, {k: v[:4] for k, v in planes.items()})
+    logits.sum().backward()
+    np.testing.assert_allclose(logits.detach().numpy(), f["dec_logits"][:4], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(p.grad.numpy(), f["dec_dlogit_dp"][:4], rtol=1e-3, atol=1e-3 * np.abs(f["dec_dlogit_dp"]).max())
+
+
+def test_trained_like_oracle_trajectory():
+    """Teacher-forced Adam steps of the oracle from the reference's states at t = 1, 10, 100 (B = 8) and 10 free steps."""
+    w, f, planes = _trained()
+    for t in (0, 9, 99):
+        x = torch.from_numpy(f[f"traj{t}_x"]).clone().requires_grad_()
+        O.losses(w, x, planes, 500.0)[0].backward()
+        g_ref = f[f"traj{t}_g"]
+        assert np.abs(x.grad.numpy() - g_ref).max() / np.abs(g_ref).max() < 2e-5
+        x1, _, _ = O.adam_step(x.detach(), x.grad, torch.from_numpy(f[f"traj{t}_m"]), torch.from_numpy(f[f"traj{t}_v"]), t + 1)
+        assert np.abs(x1.numpy() - f[f"traj{t}_x_next"]).max() < 2e-6
+    out = O.optimize_points(w, torch.from_numpy(f["init_points"]), planes, rep_weight=500.0, iterations=9, normalize=False)
+    assert np.linalg.norm(out.numpy() - f["traj9_x_next"], axis=-1).max() < 1e-3
