@@ -688,8 +688,8 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: not an ONet context");
-    if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K) || K > MAXK)
-        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 1024)");
+    if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 4096)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
@@ -699,14 +699,18 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = ensure_ws(ctx, knn_list_bytes(B));
+    const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (onet.hip)
+    hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : knn_list_bytes(B));
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_optimize workspace", e);
     float* ab = nullptr;
     e = onet_fold(ctx, c, B, s, &ab);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, s);
-    if (e == hipSuccess)
+    if (e == hipSuccess && large)
+        e = launch_onet_large_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
+                                       static_cast<const float*>(ctx->adam_tab), B, K, a, s);
+    else if (e == hipSuccess)
         e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
                                  static_cast<uint16_t*>(ctx->ws), ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K,
                                  a, s);

@@ -64,6 +64,9 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
                                  const OptArgs& a, hipStream_t s);
 hipError_t launch_large_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
                                   float h, float eps, hipStream_t s);
+// one Adam step from the occupancy gradients G ([B][K] float4: d loss / d xyz, BCE term): exact 5-NN + repulsion + Adam
+hipError_t launch_large_step(float* p, float* m, float* v, const void* G, int B, int K, const float* adam_tab, int step,
+                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, hipStream_t s);
 hipError_t launch_large_normalize(float* p, int B, int K, hipStream_t s);
 
 // ---- ONet-Opt (onet.hip) --------------------------------------------------------------------------------
@@ -83,6 +86,11 @@ hipError_t launch_onet_cbn(const float* w, const OnetDecOffsets& od, const float
                            hipStream_t s);
 hipError_t launch_onet_decode(const float* img, const float* small, const float* ab, const float* p, int B, int K,
                               float* logits, float* dlogit_dp, hipStream_t s);
+// clouds of MAXK < K <= LARGE_MAXK points (ONet/opt_defense.py:27 has no limit): two launches per Adam step, ws as
+// large_ws_bytes
+hipError_t launch_onet_large_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
+                                      float* loss, const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B,
+                                      int K, const OptArgs& a, hipStream_t s);
 hipError_t launch_onet_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
                                 float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
                                 unsigned long long* counters, const float* adam_tab, int B, int K, const OptArgs& a,

@@ -604,9 +604,57 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
     }
 }
 
+// ---- clouds of more than MAXK optimised points (--sample_npoint up to LARGE_MAXK; ONet/opt_defense.py:27 has no limit) --
+// The persistent kernel keeps a cloud's optimiser state in one CU's LDS (1024 points).  Larger clouds take two launches per
+// Adam step, like ConvONet's (optimize.hip, "large" section): this kernel - the decoder pass of onet_optimize_kernel, BCE seed
+// included, spread over (cloud, part) workgroups - writes every point's occupancy gradient; large_step_kernel (shared) does
+// the exact brute-force 5-NN, the repulsion terms and Adam.  Same arithmetic term by term, no certified lists.
+__global__ __launch_bounds__(OPT_THREADS, 2) void onet_large_occupancy_kernel(
+    const float* __restrict__ img, const float* __restrict__ small, const float* __restrict__ ab, const float* __restrict__ p,
+    int K, const int32_t* __restrict__ loss_batch_per_cloud, int loss_batch, float thr, f32x4* __restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    onet_prologue(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);
+    const float* pc = p + (size_t)cloud * K * 3;
+    const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
+    const float inv_lb = 1.0f / (float)lb;
+    const int npass = (K + 127) >> 7;
+    for (int g = blockIdx.y; g < npass; g += gridDim.y) {          // (block-uniform trip count: onet_pass syncs the block)
+        const int pt = g * 128 + wave * 16 + (lane & 15), tp = min(pt, K - 1);
+        float logit, bce, dx[3];
+        onet_pass<OMODE_OPT, true>(img, smem, wave, lane, pc[3 * tp], pc[3 * tp + 1], pc[3 * tp + 2], thr, inv_lb, logit, bce, dx);
+        if (lane < 16 && pt < K) G[(size_t)cloud * K + pt] = f32x4{dx[0], dx[1], dx[2], bce};
+    }
+}
+
+hipError_t launch_onet_large_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
+                                      float* loss, const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B,
+                                      int K, const OptArgs& a, hipStream_t s) {
+    f32x4* G = static_cast<f32x4*>(ws);
+    if (m == nullptr) {                    // own moments behind G (large_ws_bytes), zeroed
+        m = reinterpret_cast<float*>(G + (size_t)B * K);
+        v = m + (size_t)B * K * 3;
+        hipError_t e = hipMemsetAsync(m, 0, (size_t)B * K * 3 * 4 * 2, s);
+        if (e != hipSuccess) return e;
+    }
+    const int npass = (K + 127) >> 7;
+    const int parts = B >= 256 ? 1 : min(npass, max(1, 512 / B));        // enough workgroups to fill the GPU with few clouds
+    for (int step = 0; step < a.steps; ++step) {
+        hipLaunchKernelGGL(onet_large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, p, K,
+                           loss_batch_per_cloud, a.loss_batch, a.threshold, G);
+        hipError_t e = launch_large_step(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a,
+                                         step == a.steps - 1 ? loss : nullptr, s);
+        if (e != hipSuccess) return e;
+    }
+    return a.normalize ? launch_large_normalize(p, B, K, s) : hipGetLastError();
+}
+
 hipError_t configure_onet_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_decode_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_large_occupancy_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);

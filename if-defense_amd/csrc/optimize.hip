@@ -1657,6 +1657,16 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
     return hipGetLastError();
 }
 
+// One Adam step of the large-cloud path for any decoder (ConvONet above, ONet in onet.hip): G holds the occupancy gradient
+// of every point (f32x4: d loss / d xyz, BCE term), large_step_kernel does the exact 5-NN, the repulsion terms and Adam.
+hipError_t launch_large_step(float* p, float* m, float* v, const void* G, int B, int K, const float* adam_tab, int step,
+                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, hipStream_t s) {
+    const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
+    hipLaunchKernelGGL(large_step_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LDS, s, p, m, v, static_cast<const f32x4*>(G), K,
+                       adam_tab, step, loss_batch_per_cloud, a.loss_batch, a.rep_weight, rc, loss);
+    return hipGetLastError();
+}
+
 hipError_t launch_large_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
                                   float h, float eps, hipStream_t s) {
     RepConst rc = {radius, h, eps};

@@ -124,7 +124,7 @@ def check_supported(cfg, model="convonet"):
 
 
 # Sizes the kernels hold in LDS (include/ifd.h): more than the reference's Python needs, but finite.
-MAX_SAMPLE_NPOINT = {"convonet": 4096, "onet": 1024}   # optimised points per cloud (ConvONet: > 1024 takes the two-launch-per-step path)
+MAX_SAMPLE_NPOINT = {"convonet": 4096, "onet": 4096}   # optimised points per cloud (> 1024 takes the two-launch-per-step path)
 MAX_INPUT_POINTS = 4096       # points per input cloud (SOR / preprocess)
 MAX_ENCODER_POINTS = 1024     # data.pointcloud_n, the encoder subset
 

@@ -6,7 +6,12 @@ import bench
 import ifdefense_amd as I
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2468
-r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device="cuda:0")
+if os.environ.get("IFD_WEIGHTS") == "trained":      # the converged-surface regime (tests/golden/train_trained_like.py)
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trained_like_f16.npz"))
+    r = I.Restorer(I.weights.pack_state_dict({k: z[k].astype(np.float32) for k in z.files}), device="cuda:0")
+else:
+    r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device="cuda:0")
 x = torch.from_numpy(bench.synth_clouds(n)).cuda()
 keep = r.sor(x)
 prep = r.prepare(x, keep, seed=1234)
