@@ -779,17 +779,30 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
     if (scan_every_step) {
         knn_scan2(X, K, pa, pb, ta, tb);
     } else {
-        const bool force = step == 0 || rebuild_flag[step & 1] != 0;      // block-uniform
+        // A whole-cloud rebuild (new epoch) only when more than IFD_REBUILD_MIN long-lived certificates are about to expire;
+        // fewer are refreshed individually by their own waves like the fragile ones (~250 instructions per list against
+        // ~300 k cycles per wave for the rebuild).  Round 3, kernel launch of the bench workload / 512 clouds on the
+        // trained-like field (ms): 0: 829.9 / 182.1, 4: 824.3 / 179.9, 16: 825.5 / 176.9, 64: 831.9 / 174.6 (whole-cloud
+        // rebuilds per cloud on the trained-like field 12.8 -> 9.7 -> 8.1 -> 6.9).
+#ifndef IFD_REBUILD_MIN
+#define IFD_REBUILD_MIN 16
+#endif
+        const bool force = step == 0 || rebuild_flag[step & 1] > IFD_REBUILD_MIN;      // block-uniform
         float dmax = 0.f, mv = 0.f;
 #pragma unroll
         for (int w = 0; w < (S > 1 ? MAX_WAVES : OWN_WAVES); ++w) {      // (split clouds: slots 8 ... hold the other members' maxima)
             dmax = fmaxf(dmax, dmaxbuf[(step & 1) * MAX_WAVES + w]);
             mv = fmaxf(mv, movebuf[(step & 1) * MAX_WAVES + w]);
         }
-        // the certificate must survive one more step: r5 grows <= 2 mv, own and the others' displacement <= mv each
-        // (mv = largest move of the step just taken; a larger next move only costs an exact scan, never correctness)
+        // Will the certificate survive one more step?  The analytic bound is 4 mv (r5 grows <= 2 mv, own and the others'
+        // displacement <= mv each; mv = largest move of the step just taken).  A certificate that does fail only costs an
+        // exact per-point query (knn_resolve_failures, ~1 us), never correctness, while a soft failure of a long-lived
+        // certificate triggers a whole-cloud rebuild (~300 k cycles per wave) - so the margin is tuned, not derived.
+        // Round 3, kernel launch of the bench workload / 512 clouds on the trained-like field (ms): 4 mv 836.6 / 186.5,
+        // 3 mv 832.3, 2 mv 830.7, 1 mv 828.0 / 182.1, 0.5 mv 827.2 / 182.8, 0: 826.8 / 184.2 (certificate failures 4.6 k ->
+        // 19 k -> 33 k -> 46 k per 512 clouds on the trained-like field).
 #ifndef IFD_SOFT_SLACK
-#define IFD_SOFT_SLACK 4.f
+#define IFD_SOFT_SLACK 1.f
 #endif
         const float soft_slack = IFD_SOFT_SLACK * mv;
         TRACE_STAMP(25, "s_waitcnt lgkmcnt(0)");              // flags and displacement maxima read
@@ -911,10 +924,12 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
         kb.r5p = sqrtf(tb.d4);
         // a certificate about to expire: fragile ones are refreshed individually next step, the others
         // mean the epoch is old -> whole-cloud rebuild next step
-        ka.pend = !soft_a && ka.frag;
-        kb.pend = !soft_b && kb.frag;
-        const bool soft_ok = (soft_a || ka.frag) && (soft_b || kb.frag);
-        if (__any(!soft_ok) && lane == 0) rebuild_flag[(step + 1) & 1] = 1;
+        // (rebuild_flag counts the long-lived certificates about to expire; up to IFD_REBUILD_MIN of them are refreshed
+        // individually like the fragile ones instead of starting a new epoch for the whole cloud)
+        ka.pend = !soft_a && (ka.frag || IFD_REBUILD_MIN > 0);
+        kb.pend = !soft_b && (kb.frag || IFD_REBUILD_MIN > 0);
+        const int nbad = __popcll(__ballot(!soft_a && !ka.frag)) + __popcll(__ballot(!soft_b && !kb.frag));
+        if (nbad != 0 && lane == 0) atomicAdd(const_cast<int*>(rebuild_flag) + ((step + 1) & 1), nbad);
         PROF_ACC(pc_eval);
     }
     rep_point2<S>(X, F, K, pa, pb, ta, tb, rc, rep_loss_a, rep_loss_b, cv);

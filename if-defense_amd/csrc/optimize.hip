@@ -1140,9 +1140,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 dmaxbuf[np * MAX_WAVES + OWN_WAVES + tid_s] = mine ? 0.f : coop_ld(&cv.ws->scal[tid_s][0]);
                 movebuf[np * MAX_WAVES + OWN_WAVES + tid_s] = mine ? 0.f : coop_ld(&cv.ws->scal[tid_s][1]);
             }
-            if (tid_s >= 64 && tid_s < 64 + S && tid_s - 64 != member &&
-                __hip_atomic_load(&cv.ws->flag[tid_s - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                rebuild_flag[np] = 1;
+            if (tid_s >= 64 && tid_s < 64 + S && tid_s - 64 != member) {     // the other members' expiring certificates
+                const int nbad = __hip_atomic_load(&cv.ws->flag[tid_s - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (nbad != 0) atomicAdd(const_cast<int*>(rebuild_flag) + np, nbad);
+            }
             __syncthreads();
         }
         PROF_ACC(pc_adam);
