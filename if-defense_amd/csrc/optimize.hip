@@ -1588,11 +1588,10 @@ hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, 
     }
     if (split == 1 || K < 256) return IFD_PART(1, 0, B);      // (tiny clouds: nothing to share out)
     const int full = (B / n_cu) * n_cu, rest = B - full;
+    if (rest == 0 || 2 * rest > n_cu) return IFD_PART(1, 0, B);      // (more than half a round: two split launches take as long as the one round)
     if (full > 0) e = IFD_PART(1, 0, full);
-    if (e != hipSuccess || rest == 0) return e;
-    if (4 * rest <= n_cu) return IFD_PART(4, full, rest);
-    if (2 * rest <= n_cu) return IFD_PART(2, full, rest);
-    return IFD_PART(1, full, rest);      // (more than half a round: two split launches take as long as the one round)
+    if (e != hipSuccess) return e;
+    return 4 * rest <= n_cu ? IFD_PART(4, full, rest) : IFD_PART(2, full, rest);
 #undef IFD_PART
 }
 
