@@ -6,7 +6,7 @@ SURVEY section 8c: the ONet-Mesh path (row N3) uses two Cython/C++ extensions of
 (marching cubes).  They compile from their own few source files with Cython + g++ (no reference build system, no
 stand-ins): the sources are compiled WHERE THEY LIE under /root/reference, only the build products go to
 ``oracle/_ref/`` (git-ignored; they travel to the GPU box like our own .so files).  Used by the tests to validate
-``oracle/mise_oracle.py`` and the HIP mesh path; nothing in the product imports them.
+``oracle/mesh_oracle.py`` (the Python around them) and the HIP mesh path; nothing in the product imports them.
 
     python oracle/build_ref.py        (needs /root/reference; a no-op with a message otherwise)
 """
