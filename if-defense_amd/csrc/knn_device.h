@@ -544,9 +544,12 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
 // Fixed-point accumulator of the repulsion gradient in LDS (optimiser kernels).  The neighbour -> point scatter of
 // index_points' backward (repulsion_loss.py:43-47) is the one place where many threads add into the same point; LDS
 // float atomics would make the sum depend on their order.  Integer sums do not: every term is rounded to a multiple of
-// 2^-23 (its magnitude is bounded by ~7: |d loss / d d| <= w (1 + (r - d) 2 d / h^2)), x and y share one 64-bit word (x in
-// the high half; the halves' sums separate exactly as long as each stays inside 32 bits: |sum| < 256), z has a 32-bit
-// word.  12 bytes of atomics per term instead of 24 (the phase is bound by LDS atomic throughput, not by arithmetic), 3
+// 2^-23, x and y share one 64-bit word (x in the high half; the halves' sums separate exactly as long as each stays inside
+// 32 bits: |sum| < 256), z has a 32-bit word.  Headroom: a term's magnitude is |d loss / d d| = w (1 + (r - d) 2 d / h^2)
+// <= 1.4 with the reference's r = 0.07, h = 0.03 (maximum near d = h; coincident points contribute 0), a point receives its
+// own five centre terms plus one term from every point that counts it among its 5 nearest, and the in-degree of a 5-NN
+// graph in three dimensions is at most 5 x 12 (kissing number): |sum| <= 65 x 1.4 = 91 < 256, whatever the input
+// (test_repulsion_accumulators_do_not_wrap_on_a_tight_cluster holds the kernel against ifd_repulsion's 64-bit sums).  12 bytes of atomics per term instead of 24 (the phase is bound by LDS atomic throughput, not by arithmetic), 3
 // conversion instructions per component instead of 11, 12 KB of LDS instead of 24.
 struct RepAcc {
     long long* xy;       // [MAXK]

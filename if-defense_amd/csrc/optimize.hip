@@ -27,7 +27,7 @@
 #include "knn_device.h"
 
 namespace ifd {
-constexpr int IFD_TRACE_BASE = 16;      // first trace slot in the device counter buffer (= IFD_N_COUNTERS)
+[[maybe_unused]] constexpr int IFD_TRACE_BASE = 16;      // first trace slot in the device counter buffer (= IFD_N_COUNTERS)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));

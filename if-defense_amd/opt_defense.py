@@ -42,6 +42,9 @@ def build_parser(model="convonet"):
     # additions
     parser.add_argument('--seed', type=int, default=0, help='seed of the counter-based random draws')
     parser.add_argument('--weights', type=str, default='', help='checkpoint (.pth); default: cfg test.model_file')
+    parser.add_argument('--printing', type=str2bool, default=False,
+                        help='print the losses every 100 iterations like the reference does (opt_defense.py:229-236; '
+                             'off by default: every print is a device synchronisation)')
     return parser
 
 
@@ -194,7 +197,7 @@ def main(argv=None, model="convonet", restorer_factory=None, backend=None, devic
     dargs = DefenseArgs(sample_npoint=args.sample_npoint, padding_scale=args.padding_scale, init_sigma=args.init_sigma,
                         iterations=args.iterations, batch_size=args.batch_size, lr=args.lr, rep_weight=args.rep_weight,
                         sor=args.sor, sor_k=args.sor_k, sor_alpha=args.sor_alpha, threshold=cfg['test']['threshold'],
-                        input_npoint=cfg['data']['pointcloud_n'], seed=args.seed)
+                        input_npoint=cfg['data']['pointcloud_n'], seed=args.seed, printing=args.printing)
 
     def defend(pc):
         # compute the local shard -> agreement (raises D.AgreedFailure on every rank if one rank's compute failed) -> all-gather

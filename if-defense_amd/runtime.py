@@ -244,33 +244,42 @@ class Restorer:
         return out if len(out) > 1 else p
 
     def _optimize_points_printing(self, opt_points, c, rep_weight, n_steps, lr, loss_batch, normalize, scan):
-        """printing=True of the reference's optimize_points (opt_defense.py:229-236): the losses of iterations 0, 100,
-        200, ... are printed.  The run is cut into segments that END on those iterations (the kernel reports the losses of
-        a launch's last step) and carries the Adam state across; the result is bit-identical to the uncut run (the
-        neighbour lists are exact at every step, the moments are passed on as they are)."""
+        """printing=True of the reference's optimize_points (opt_defense.py:229-236): at iterations 0, 100, 200, ... it
+        prints the loss, the two loss terms and the mean occupancy probability, all evaluated at that iteration's
+        pre-update points.  The run is cut so that every such iteration is a launch of its own (the kernel reports the
+        losses of a launch's last step; the probability comes from one ifd_decode of the points it starts from) and the
+        Adam state is carried across: the result is bit-identical to the uncut run (the neighbour lists are exact at every
+        step, the moments are passed on as they are).
+        Scaling: the reference prints per BATCH of `batch_size` clouds; a device pass here may hold several reference
+        batches (or a shard of one), so the printed terms are the means over this pass's clouds of the per-cloud terms -
+        equal to the reference's scalars when the pass is exactly one reference batch, their average otherwise."""
         p, st, t = opt_points, None, 0
         B = opt_points.shape[0]
-        lb_mean = None
         while t < n_steps:
-            seg = 1 if t == 0 else min(100, n_steps - t)
-            last = t + seg == n_steps
-            res = self.optimize_points(p, c, rep_weight=rep_weight, steps=seg, lr=lr, loss_batch=loss_batch,
-                                       normalize=normalize and last, state=st, return_state=True, return_loss=True,
-                                       knn_scan_every_step=scan)
-            p, st, loss = res
-            t += seg
-            it = t - 1
-            if it % 100 == 0:
-                l = loss.double().cpu()
-                if torch.is_tensor(loss_batch):
-                    lbv = loss_batch.double().cpu()
-                else:
-                    lbv = torch.full((B,), float(loss_batch or B), dtype=torch.float64)
-                # per-cloud terms carry their own 1/B; the reference's scalars are sums over the batch of B clouds
-                occ = float((l[:, 0]).sum()) * float(B) / float(lbv.sum()) if lbv.numel() else 0.0
-                rep = float(l[:, 1].mean()) * rep_weight
-                print('iter {}, loss {:.4f}'.format(it, occ + rep))
-                print('occ loss: {:.4f}, rep loss: {:.4f}'.format(occ, rep))
+            nxt = t if t % 100 == 0 else min(n_steps, (t // 100 + 1) * 100)     # next printing iteration (or the end)
+            if nxt > t:                                                          # plain steps up to it
+                last = nxt == n_steps
+                p, st = self.optimize_points(p, c, rep_weight=rep_weight, steps=nxt - t, lr=lr, loss_batch=loss_batch,
+                                             normalize=normalize and last, state=st, return_state=True,
+                                             knn_scan_every_step=scan)
+                t = nxt
+                continue
+            prob = float(torch.sigmoid(self.decode(p, c)).mean())               # occ_value of iteration t (pre-update points)
+            last = t + 1 == n_steps
+            p, st, loss = self.optimize_points(p, c, rep_weight=rep_weight, steps=1, lr=lr, loss_batch=loss_batch,
+                                               normalize=normalize and last, state=st, return_state=True, return_loss=True,
+                                               knn_scan_every_step=scan)
+            l = loss.double().cpu()
+            if torch.is_tensor(loss_batch):
+                lbv = loss_batch.double().cpu()
+            else:
+                lbv = torch.full((B,), float(loss_batch or B), dtype=torch.float64)
+            # per-cloud terms carry their own 1/B; the reference's scalars are sums over the batch of B clouds
+            occ = float((l[:, 0]).sum()) * float(B) / float(lbv.sum()) if lbv.numel() else 0.0
+            rep = float(l[:, 1].mean()) * rep_weight
+            print('iter {}, loss {:.4f}'.format(t, occ + rep))
+            print('occ loss: {:.4f}, rep loss: {:.4f}\nocc value mean: {:.4f}'.format(occ, rep, prob))
+            t += 1
         return p
 
     def counters(self) -> Dict[str, int]:

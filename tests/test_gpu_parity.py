@@ -286,6 +286,50 @@ def test_automatic_split_of_a_partial_round(restorer):
         assert bool(torch.isfinite(b[0]).all())
 
 
+def test_printing_seam_matches_reference_prints(restorer, golden, planes2, capsys):
+    """optimize_points(..., printing=True) (opt_defense.py:229-236): the three printed quantities at iterations 0 and 100 -
+    loss terms against the reference's own values at those iterations, the mean occupancy probability against the oracle -
+    and a result bit-identical to the silent run."""
+    from oracle import convonet_oracle as O
+    init = torch.from_numpy(golden["init_points"][:2])
+    quiet = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=120)
+    capsys.readouterr()
+    loud = restorer.optimize_points(init, planes2, rep_weight=500.0, iterations=120, printing=True)
+    out = capsys.readouterr().out
+    assert torch.equal(quiet, loud)
+    lines = out.strip().splitlines()
+    assert [l.split(",")[0] for l in lines if l.startswith("iter")] == ["iter 0", "iter 100"], out
+    occ0 = float(lines[1].split("occ loss:")[1].split(",")[0])
+    rep0 = float(lines[1].split("rep loss:")[1])
+    assert abs(occ0 - golden["traj0_loss"][0]) < 2e-4 * golden["traj0_loss"][0] and abs(rep0 - golden["traj0_loss"][1]) < 1e-3
+    prob0 = float(lines[2].split("occ value mean:")[1])
+    ref_prob = float(torch.sigmoid(torch.from_numpy(golden["dec_logits"])).mean())
+    assert abs(prob0 - ref_prob) < 1e-4, (prob0, ref_prob)
+    assert lines[3].startswith("iter 100") and "occ value mean:" in lines[5]
+
+
+def test_repulsion_accumulators_do_not_wrap_on_a_tight_cluster(restorer, golden, planes2):
+    """The optimiser accumulates the repulsion gradient in 32-bit fixed point (2^-23; x and y share a 64-bit word): a sum
+    beyond +-256 would wrap silently.  Terms are bounded by 1.4 and a point is among the 5 nearest of at most 5 x 12 others
+    (kissing number), so sums stay below ~90 - checked here on the worst case the loss allows: clouds drawn into a few
+    blobs at the distance h where the terms are largest, against ifd_repulsion's 64-bit accumulators (2^-40)."""
+    g = torch.Generator().manual_seed(3)
+    centres = (torch.rand(2, 6, 3, generator=g) - 0.5) * 0.6
+    which = torch.randint(0, 6, (2, 1024), generator=g)
+    x = torch.gather(centres, 1, which[..., None].expand(2, 1024, 3)) + 0.03 * torch.randn(2, 1024, 3, generator=g) * 0.35
+    _, grad_wide = restorer.repulsion_loss(x, want_grad=True)                 # d(sum_b loss_b)/dp, wide accumulators
+    zero = {k: torch.zeros_like(v) for k, v in planes2.items()}
+    base, (m0, _, _) = restorer.optimize_points(x, zero, rep_weight=0.0, steps=1, normalize=False, loss_batch=1, return_state=True, split=1)
+    _, (m1, _, _) = restorer.optimize_points(x, zero, rep_weight=500.0, steps=1, normalize=False, loss_batch=1, return_state=True, split=1)
+    g_rep = (m1 - m0).cpu().numpy() / 0.1 / 500.0                             # the kernel's repulsion gradient alone
+    ref = grad_wide.cpu().numpy()
+    scale = 1024 * 5.0                                                         # largest accumulated sum in fixed-point units
+    print("tight clusters: largest accumulated repulsion sum %.1f (wraps at 256), max error %.2e of max" %
+          (np.abs(ref).max() * scale, np.abs(g_rep - ref).max() / np.abs(ref).max()))
+    assert np.abs(ref).max() * scale < 128.0
+    assert np.abs(g_rep - ref).max() < 2e-5 * np.abs(ref).max()
+
+
 def test_rep_weight_zero_and_small_k(restorer, golden, planes2, oracle_weights):
     from oracle import convonet_oracle as O
     init = torch.from_numpy(golden["init_points"][:2, :100]).clone()
