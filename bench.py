@@ -221,7 +221,8 @@ def extras(dev):
         z = np.load(os.path.join(ROOT, "tests", "golden", "trained_like_f16.npz"))
         r = I.Restorer(I.weights.pack_state_dict({k: z[k].astype(np.float32) for k in z.files}), device=dev)
         n = 512                                                     # two whole rounds of one cloud per CU
-        x = torch.from_numpy(synth_clouds(n)).to(dev)
+        pool = synth_clouds(602)                                    # the six shape families the checkpoint was trained on
+        x = torch.from_numpy(pool[np.arange(602) % 7 != 6][:n]).to(dev)      # (family 6, the airplane, has no analytic occupancy)
         prep = r.prepare(x, r.sor(x), seed=1234)
         planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
         lb = torch.full((n,), 192, dtype=torch.int32, device=dev)
@@ -243,9 +244,23 @@ def extras(dev):
             "exact_query_fraction": round(c["knn_exact_evals"] / (8.0 * n * (ITERATIONS + 1)), 4),
             "occupancy_prob_abs_dev_from_threshold": {"init": round(float((p0 - 0.2).abs().mean()), 4),
                                                       "restored": round(float((p1 - 0.2).abs().mean()), 4)},
-            "what": "ifd_optimize on %d bench clouds with the trained-like checkpoint (tests/golden/trained_like_f16.npz: the "
-                    "reference model trained on analytic occupancy of the bench shapes; a field with a surface at the "
-                    "iso-value 0.2), 501 Adam steps, one workgroup per cloud" % n}
+            "what": "ifd_optimize on %d bench clouds of the six trained shape families with the trained-like checkpoint "
+                    "(tests/golden/trained_like_f16.npz: the reference model trained on analytic occupancy of those families; "
+                    "a field with a surface at the iso-value 0.2), 501 Adam steps, one workgroup per cloud" % n}
+        # the family the checkpoint never saw (the airplane): an untrained field under trained weights - the slowest clouds
+        xa = torch.from_numpy(pool[np.arange(602) % 7 == 6][:64]).to(dev)
+        pa = r.prepare(xa, r.sor(xa), seed=1234)
+        pla = r.encode_inputs(pa["sel"], pa["t_per_cloud"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r.optimize_points(pa["init"], pla, rep_weight=500.0, iterations=ITERATIONS, loss_batch=lb[:64], normalize=False, split=1)
+        e1.record()
+        torch.cuda.synchronize()
+        ca = r.counters()
+        out["trained_like"]["unseen_family"] = {
+            "ms_per_round": round(e0.elapsed_time(e1), 1), "vs_trained_families": round(e0.elapsed_time(e1) / (ms / 2.0), 3),
+            "list_rebuilds_per_cloud": round(ca["knn_rebuilds"] / 8.0 / 64, 2),
+            "what": "64 airplane clouds (one partial round, one workgroup per cloud) on the same checkpoint"}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["trained_like"] = {"error": str(e)[:200]}
