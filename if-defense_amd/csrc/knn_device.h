@@ -329,7 +329,8 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 // cost is ~1 us for loading the candidates plus ~0.5 us per target - whole-cloud rebuilds (all flagged) and the
 // individual refreshes of short-lived ("fragile") certificates share this code.  A ball that overflows its list is
 // shrunk in proportion to the overshoot (hit count ~ r^2 on a surface) and rebuilt on the spot.
-__device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, int wave, int lane,
+// pa / pb: the lane's two points (the target of lane l is read off lane l: any thread -> point mapping works).
+__device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, int pa, int pb, int lane,
                                             uint16_t* __restrict__ lists, bool need_a, bool need_b, float d4a,
                                             float d4b, KnnPt& ka, KnnPt& kb, float dbase, float mv,
                                             const KnnCounters& cn) {
@@ -353,7 +354,7 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
         while (mask != 0ull) {
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1ull;
-            const int i = (half ? OPT_THREADS : 0) + wave * 64 + l;
+            const int i = __builtin_amdgcn_readlane(half ? pb : pa, l);
             float tf = readlane_f(my_tf, l), tb = readlane_f(my_tb, l);
             const f32x4 xi = X[i];                                                   // wave-uniform address
             uint16_t* lst = lists + (size_t)i * LIST_M;
@@ -392,7 +393,7 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
             kp.al_f = fminf(fmaxf(kp.al_f, 1.1f), 6.f);
             kp.al_b = fminf(fmaxf(kp.al_b, 1.2f), 30.f);
             kp.al_f = fminf(kp.al_f, kp.al_b);
-            kp.x0 = X[(half ? OPT_THREADS : 0) + wave * 64 + lane];
+            kp.x0 = X[half ? pb : pa];
             kp.dbase = dbase;
             // expected lifetime of the certificate ~ (rho - r5 - 6 mv) / (~2 mv per step)
 #ifndef IFD_FRAG_MULT
@@ -441,7 +442,7 @@ __device__ __forceinline__ void lexmin_wave(float& bd, int& bj) {
 // lanes hold the K candidates (16 each), per target five rounds of a (distance, index)-lexicographic minimum -
 // ~500 instructions per target instead of a ~20 k-instruction scan by every lane of the wave.  Falls back to that
 // scan when many lanes failed.
-__device__ __forceinline__ void knn_resolve_failures(const f32x4* __restrict__ X, int K, int wave, int lane, int pa, int pb,
+__device__ __forceinline__ void knn_resolve_failures(const f32x4* __restrict__ X, int K, int lane, int pa, int pb,
                                                      bool fail_a, bool fail_b, Top5& ta, Top5& tb) {
     const unsigned long long ma = __ballot(fail_a), mb = __ballot(fail_b);
     if (__popcll(ma) + __popcll(mb) > 24) {
@@ -464,7 +465,7 @@ __device__ __forceinline__ void knn_resolve_failures(const f32x4* __restrict__ X
         while (mask != 0ull) {
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1ull;
-            const int i = (half ? OPT_THREADS : 0) + wave * 64 + l;
+            const int i = __builtin_amdgcn_readlane(half ? pb : pa, l);
             const f32x4 xi = X[i];
             float d[16];
 #pragma unroll
@@ -578,14 +579,15 @@ __device__ __forceinline__ void unpack_xy(long long s, int& x, int& y) {
 // the data with agent-scope loads.  (A formal agent-scope release / acquire pair adds an L2 write-back of everything the
 // XCD has dirtied - the parked scratch state of 32 workgroups - and an invalidate: 35 us per step, measured.)
 // ---------------------------------------------------------------------------------------------
+constexpr int MAX_COOP_WAVES = 16;    // owner waves of a split cloud: S members x (8 at S = 2, 4 at S = 4) = MAX_WAVES
 struct CoopWs {
     f32x4 X[MAXK];                    // positions after the last Adam step (written by the owners)
     long long Fxy[MAXK];              // neighbour terms received from other members, packed like RepAcc
     int Fz[MAXK];
     float L[MAXK][2];                 // last step only: BCE term, repulsion term of every point
-    float scal[8][2];                 // per (virtual) owner wave: displacement maximum, step-length maximum of the next step
+    float scal[MAX_COOP_WAVES][2];    // per owner wave of the cloud: displacement maximum, step-length maximum of the next step
     int flag[4];                      // per member: whole-cloud list rebuild requested
-    unsigned int bar_knn, bar_step;   // arrivals: owner waves that finished their kNN phase; members that finished their step
+    unsigned int bar_knn, bar_step;   // arrivals: members that have sent their neighbour terms; members that finished their step
     unsigned int pad[2];
 };
 struct CoopView {
@@ -606,16 +608,31 @@ __device__ __forceinline__ void coop_wait(unsigned int* ctr, unsigned int target
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-// one neighbour (or centre) term into the accumulators of point j: LDS if this workgroup owns j, else the owner's global ones
+// one neighbour (or centre) term into the accumulators of point j.  Split clouds accumulate the terms of points another
+// member owns in their OWN LDS entries for those points first (unused otherwise) and send every entry once per step
+// (coop_flush_remote): 20 scattered agent-scope atomics per lane in the middle of the phase measured 22 k cycles per step.
 template <int S>
 __device__ __forceinline__ void rep_scatter(const RepAcc F, const CoopView cv, int j, int fx, int fy, int fz) {
-    if (coop_owns<S>(j, cv.member)) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + j), (unsigned long long)pack_xy(fx, fy));
-        atomicAdd(F.z + j, fz);
-    } else {
-        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cv.ws->Fxy + j), (unsigned long long)pack_xy(fx, fy),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(cv.ws->Fz + j, fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(reinterpret_cast<unsigned long long*>(F.xy + j), (unsigned long long)pack_xy(fx, fy));
+    atomicAdd(F.z + j, fz);
+}
+// what this member's points sent to points of other members: one coalesced pass of integer atomics onto the owners' global
+// accumulators (one wave, after every owner wave of the member has finished its repulsion terms), entries cleared
+template <int S>
+__device__ __forceinline__ void coop_flush_remote(const RepAcc F, const CoopView cv, int K, int lane) {
+    for (int j = lane; j < K; j += 64) {
+        if (coop_owns<S>(j, cv.member)) continue;
+        const long long fxy = F.xy[j];
+        const int fz = F.z[j];
+        if (fxy != 0) {
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cv.ws->Fxy + j), (unsigned long long)fxy,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            F.xy[j] = 0;
+        }
+        if (fz != 0) {
+            __hip_atomic_fetch_add(cv.ws->Fz + j, fz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            F.z[j] = 0;
+        }
     }
 }
 
@@ -639,9 +656,13 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const Re
         int f[2][3];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            // hipcc contracts a * b + c into an fma wherever it likes (-ffp-contract=fast ignores pragmas), and it likes
+            // different places in the one-chain instantiation of split clouds and in this two-chain one.  So every
+            // multiply-add below is SPELLED as an fma and no product is left next to an add it could be fused into: the
+            // bits do not depend on the instantiation.
             const f32x4 xi = s ? xb : xa, xj = s ? qb : qa;
             const float ex = xj.x - xi.x, ey = xj.y - xi.y, ez = xj.z - xi.z;
-            const float d2raw = ex * ex + ey * ey + ez * ez;
+            const float d2raw = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
             const float d2 = fmaxf(d2raw, rc.eps);
             // sqrt, 1 / h, 1 / d and exp through the hardware instructions (v_sqrt_f32, v_rcp_f32, v_exp_f32: 1 ulp each)
             // instead of the IEEE expansions (~10 dependent instructions per divide / sqrt, ~15 per expf; -DIFD_EXACT_REP
@@ -653,15 +674,17 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const Re
             const float ih = __builtin_amdgcn_rcpf(rc.h);
             const float q = d * ih;
             const float w = __expf(-(q * q));
-            (s ? lb : la) += (rc.radius - d) * w;
-            const float dd = -w - (rc.radius - d) * w * (2.f * q * ih);
+            const float rd = rc.radius - d, rw = rd * w;
+            (s ? lb : la) = __builtin_fmaf(rd, w, s ? lb : la);
+            const float dd = __builtin_fmaf(-rw, (q + q) * ih, -w);
             const float coef = d2raw > rc.eps ? dd * __builtin_amdgcn_rcpf(d) : 0.f;
 #else
             const float d = sqrtf(d2);
             const float q = d / rc.h;
             const float w = expf(-(q * q));
-            (s ? lb : la) += (rc.radius - d) * w;
-            const float dd = -w - (rc.radius - d) * w * (2.f * q / rc.h);
+            const float rd = rc.radius - d, rw = rd * w;
+            (s ? lb : la) = __builtin_fmaf(rd, w, s ? lb : la);
+            const float dd = __builtin_fmaf(-rw, (q + q) / rc.h, -w);
             const float coef = d2raw > rc.eps ? dd / d : 0.f;
 #endif
             f[s][0] = fix32(coef * ex);
@@ -765,7 +788,6 @@ struct KnnShared {
 
 // kNN + repulsion of the two points (pa, pb) this lane owns, for one optimiser step (all lanes of an owner wave call
 // it together).  Leaves the loss terms in rep_loss_a/b and scatters the neighbour AND centre gradients into F (fixed point).
-// `wave` is the wave's index among the cloud's eight owner waves (= its index in the workgroup unless the cloud is split).
 template <int S = 1>
 __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
                                           int wave, int lane, int step, bool last, bool scan_every_step,
@@ -843,7 +865,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
                 d4a = ra * ra;
                 d4b = rb * rb;
             }
-            knn_refresh(X, K, wave, lane, cloud_lists, need_a, need_b, d4a, d4b, ka, kb, dmax, mv, cn);
+            knn_refresh(X, K, pa, pb, lane, cloud_lists, need_a, need_b, d4a, d4b, ka, kb, dmax, mv, cn);
         }
         ka.pend = kb.pend = false;
         PROF_ACC(pc_build);
@@ -898,7 +920,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
             if (__any(amb_a || amb_b)) cn.bump(CN_EXACT);
             if (__builtin_expect(__any(fail_a || fail_b), 0)) cn.bump(CN_BRUTE);      // certificate failed
             if (__any(fail_a || fail_b || amb_a || amb_b))     // exact query for those points, this step
-                knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a || amb_a, fail_b || amb_b, ta, tb);
+                knn_resolve_failures(X, K, lane, pa, pb, fail_a || amb_a, fail_b || amb_b, ta, tb);
             }
         }
         if (exact) {
@@ -917,7 +939,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
                 const bool fail_b = pb < K && !(kb.cnt_b >= 0 && r5b < (kb.rho_b - hs_b) * 0.99999f - 1e-7f);
                 if (__builtin_expect(__any(fail_a || fail_b), 0)) {
                     cn.bump(CN_BRUTE);
-                    knn_resolve_failures(X, K, wave, lane, pa, pb, fail_a, fail_b, ta, tb);
+                    knn_resolve_failures(X, K, lane, pa, pb, fail_a, fail_b, ta, tb);
                 }
                 soft_a = pa >= K || ka.cnt_b < 0 || r5a < (ka.rho_b - spent_a) * 0.99999f - 1e-7f - soft_slack;
                 soft_b = pb >= K || kb.cnt_b < 0 || r5b < (kb.rho_b - spent_b) * 0.99999f - 1e-7f - soft_slack;
@@ -982,18 +1004,20 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             F.z[pt] = 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
+                // (every multiply-add spelled as an fma, see rep_point2: the one- and the two-point instantiations of this
+                // function must agree bit for bit)
                 const float gn = (float)fi[a] * FIX32_INV;
-                const float gr = gn * rep_scale;
-                const float g = gocc[a] + gr;
+                const float g = __builtin_fmaf(gn, rep_scale, gocc[a]);
                 float& mr = mm[3 * q + a];
                 float& vr = vv[3 * q + a];
-                mr = mr + (g - mr) * (1.f - 0.9f);
-                vr = vr * 0.999f + (1.f - 0.999f) * g * g;
+                mr = __builtin_fmaf(g - mr, 1.f - 0.9f, mr);                             // lerp_(grad, 1 - beta1)
+                vr = __builtin_fmaf((1.f - 0.999f) * g, g, vr * 0.999f);                 // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
                 // IEEE sqrt and divisions, like torch's kernels (the hardware v_sqrt_f32 / v_rcp_f32 forms measured -0.25 %
                 // of the kernel on the bench workload: not taken for the update itself)
                 const float denom = sqrtf(vr) / bc2 + 1e-8f;
-                const float upd = step_size * (mr / denom);
-                xs[a] = xs[a] - upd;
+                const float ratio = mr / denom;
+                const float upd = step_size * ratio;
+                xs[a] = __builtin_fmaf(-step_size, ratio, xs[a]);                        // addcdiv_(exp_avg, denom, value = -step_size)
                 msq = fmaf(upd, upd, msq);
                 xnew[q][a] = xs[a];
             }

@@ -896,8 +896,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists,
     unsigned long long* __restrict__ counters, const float* __restrict__ adam_tab, int K, OptArgs A,
     CoopWs* __restrict__ coop, int n_clouds) {
-    constexpr int OT = OPT_THREADS / S;               // owner threads of this workgroup (two points each)
-    constexpr int OW = OWN_WAVES / S;                 // ... and owner waves
+    // Owner threads.  One workgroup per cloud: 512 threads x two points (pa = t, pb = t + 512).  Split clouds: ONE point per
+    // thread, so that the neighbour / Adam duty of the member's 1024 / S points is spread over as many waves as possible
+    // (S = 2: all eight, S = 4: four) - with two points per thread only 8 / S waves had that duty, each as long as in the
+    // unsplit kernel, and the phase did not shrink with S.  (The second chain of the interleaved kNN code then runs on a dummy
+    // point, lane by lane.  Compiling it OUT - half the key networks - measured 53.4 / 36.3 ms against 47.7 / 30.3 at S = 2 /
+    // 4, also with the one point's entries spread over two networks for the same instruction-level parallelism.)
+    constexpr int PTS = MAXK / S;                     // points of this member
+    constexpr int OT = S == 1 ? OPT_THREADS : (PTS < OPT_THREADS ? PTS : OPT_THREADS);      // owner threads
+    constexpr int OW = OT / 64;                       // ... and owner waves
+    K = K < MAXK ? K : MAXK;                          // (the launcher guarantees it; spelled out so that pb < K folds to false)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
     f32x4* G = reinterpret_cast<f32x4*>(smem + DEC_FLOATS);          // occupancy gradient (+ BCE term in .w)
@@ -918,9 +926,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const float* pl = planes + (size_t)cloud * (A.planes_shared ? 0 : CLOUD_PLANE_FLOATS);
     float* pc = p + (size_t)cloud * K * 3;
     const bool owner = tid < OT;
-    const int pa = owner ? member * OT + tid : MAXK, pb = owner ? member * OT + tid + OPT_THREADS : MAXK;   // the two points this thread owns
+    // the point(s) of owner thread t: member m of a split cloud holds {m PTS/2 + u, 512 + m PTS/2 + u : u < PTS/2} (coop_owns)
+    auto point_a = [&](int t) {
+        return S == 1 ? t : (t < PTS / 2 ? member * (PTS / 2) + t : OPT_THREADS + member * (PTS / 2) + (t - PTS / 2));
+    };
+    const int pa = owner ? point_a(tid) : MAXK, pb = (S == 1 && owner) ? tid + OPT_THREADS : MAXK;
     constexpr int NT = 32 / S, NTH = 16 / S;        // 32-point decoder tiles of this workgroup: NTH in each half of the cloud
-    auto tile_base = [&](int t) { return (t / NTH) * OPT_THREADS + member * OT + (t % NTH) * 32; };
+    auto tile_base = [&](int t) { return (t / NTH) * OPT_THREADS + member * (PTS / 2) + (t % NTH) * 32; };
 
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
@@ -970,15 +982,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     float* movebuf = scratch + 64;                                   // [2][MAX_WAVES] per-wave max single-step move
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
     int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
+    int* knn_done = reinterpret_cast<int*>(scratch + 31);            // split clouds: owner waves of this member past their kNN phase
     unsigned int* lcnt = reinterpret_cast<unsigned int*>(scratch + 96);           // [CN_COUNT] event counters
     const KnnShared ksh = {dmaxbuf, movebuf, rebuild_flag};
 
     if (tid < 2) rebuild_flag[tid] = 0;
-    if (tid == 0) *tile_ctr = 0;
+    if (tid == 0) { *tile_ctr = 0; *knn_done = 0; }
     if (tid < CN_COUNT) lcnt[tid] = 0u;
-    if (tid < 2 * MAX_WAVES) {      // (split clouds: slots [0, OW) this member's owner waves, [8, 16) the other members')
+    if (tid < 2 * MAX_WAVES) {
         dmaxbuf[tid] = 0.f;
-        movebuf[tid] = (S == 1 || (tid & (MAX_WAVES - 1)) < OW || (tid & (MAX_WAVES - 1)) >= OWN_WAVES) ? 2.f * A.lr : 0.f;
+        movebuf[tid] = (tid & (MAX_WAVES - 1)) < S * OW ? 2.f * A.lr : 0.f;      // (slot = owner wave of the CLOUD: member * OW + wave)
     }
     __syncthreads();
 #ifdef IFD_PROF
@@ -997,7 +1010,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         asm volatile("" : "+v"(tid_s));
         const int lane = tid_s & 63, wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
         const bool owner = tid_s < OT;
-        const int pa = owner ? member * OT + tid_s : MAXK, pb = owner ? member * OT + tid_s + OPT_THREADS : MAXK;
+        const int pa = owner ? point_a(tid_s) : MAXK, pb = (S == 1 && owner) ? tid_s + OPT_THREADS : MAXK;
 #if defined(IFD_PROF)
         KnnCounters cn{lcnt, lane, lprof + wave * PC_COUNT};
 #elif defined(IFD_TRACE)
@@ -1041,10 +1054,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #endif
             }
         };
-        if (S > 1) { PROF_T0(); run_tiles(); }
+#ifndef IFD_SPLIT_KNN_PRIO
+#define IFD_SPLIT_KNN_PRIO 2          // 0: tiles first (kNN at the end of the step); 1 / 2 / 3: kNN first at that wave priority
+#endif
+        if (S > 1 && IFD_SPLIT_KNN_PRIO == 0) { PROF_T0(); run_tiles(); }
         // ---- kNN + repulsion of the points this wave owns (all waves at the same time: a VALU-only wave next to an
         //      MFMA-heavy tile wave on a SIMD is starved, f32 MFMA and VALU issue do not overlap on gfx950) -------------
         if (wave < OW && use_rep) {
+            if (S > 1 && IFD_SPLIT_KNN_PRIO == 1) asm volatile("s_setprio 1");
+            if (S > 1 && IFD_SPLIT_KNN_PRIO == 2) asm volatile("s_setprio 2");
+            if (S > 1 && IFD_SPLIT_KNN_PRIO == 3) asm volatile("s_setprio 3");
             float rep_loss_a, rep_loss_b;
             KnnPt ka, kb;
             const int z = opaque_zero();
@@ -1053,18 +1072,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             TRACE_STAMP(24, "s_waitcnt vmcnt(0)");            // parked state back from scratch
             uint16_t* La = cloud_lists + (size_t)(pa & (MAXK - 1)) * LIST_M;
             uint16_t* Lb = cloud_lists + (size_t)(pb & (MAXK - 1)) * LIST_M;
-            knn_phase<S>(X, F, K, pa, pb, member * OW + wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb,
+            knn_phase<S>(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb,
                          cloud_lists, ka, kb, ksh, rc, rep_loss_a, rep_loss_b, cn, cv);
             const int z2 = opaque_zero();
             park_knnpt(park, z2, PARK_KNN, ka);
             park_knnpt(park, z2, PARK_KNN + 4, kb);
             if (want_loss) park[z2 + PARK_KNN + 3] = f32x4{rep_loss_a, rep_loss_b, 0.f, 0.f};
-            if (S > 1) {       // this wave's neighbour terms are on their way to the other members' accumulators
-                coop_publish();
-                if (lane == 0) coop_arrive(&cv.ws->bar_knn);
+            if (S > 1) {       // the member's last owner wave sends what its points owe to points of the other members
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wave's LDS atomics are done
+                int done = 0;
+                if (lane == 0) done = atomicAdd(knn_done, 1);
+                if (__builtin_amdgcn_readfirstlane(done) == OW - 1) {
+                    coop_flush_remote<S>(F, cv, K, lane);
+                    coop_publish();
+                    if (lane == 0) { *knn_done = 0; coop_arrive(&cv.ws->bar_knn); }
+                }
+                if (IFD_SPLIT_KNN_PRIO != 0) asm volatile("s_setprio 0");
             }
         }
-        if (S == 1) { PROF_T0(); run_tiles(); }
+        if (S == 1 || IFD_SPLIT_KNN_PRIO != 0) { PROF_T0(); run_tiles(); }
         PROF_ACC(pc_tiles);
         // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------
         AdamState ast;
@@ -1076,7 +1102,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         const f32x4 rl = park[z3 + PARK_KNN + 3];
         const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
         // split clouds: every owner wave of the cloud has sent its neighbour terms (the wait rode under the decoder tiles)
-        if (S > 1 && use_rep && wave == 0) coop_wait(&cv.ws->bar_knn, (unsigned int)(OWN_WAVES * (step + 1)));
+        if (S > 1 && use_rep && wave == 0) coop_wait(&cv.ws->bar_knn, (unsigned int)(S * (step + 1)));
         __syncthreads();
         PROF_ACC(pc_wait);
         if (S > 1 && want_loss) {   // the last step's per-point loss terms, reduced over the whole cloud after the loop
@@ -1110,7 +1136,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
         TRACE_STAMP(29, "s_waitcnt lgkmcnt(0)");              // PIX written
         if (owner) store_adam(MV, tid_s, ast);
-        adam_displacement(K, pa, pb, wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
+        adam_displacement(K, pa, pb, member * OW + wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
         if (S == 1) {
             if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
             __syncthreads();
@@ -1118,8 +1144,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             // ---- the step's exchange between the members of a split cloud ------------------------------------------------
             const int np = (step + 1) & 1;
             if (wave < OW && lane == 0) {      // this owner wave's certificate maxima of the next step (adam_displacement)
-                coop_st(&cv.ws->scal[member * OW + wave][0], dmaxbuf[np * MAX_WAVES + wave]);
-                coop_st(&cv.ws->scal[member * OW + wave][1], movebuf[np * MAX_WAVES + wave]);
+                coop_st(&cv.ws->scal[member * OW + wave][0], dmaxbuf[np * MAX_WAVES + member * OW + wave]);
+                coop_st(&cv.ws->scal[member * OW + wave][1], movebuf[np * MAX_WAVES + member * OW + wave]);
             }
             if (tid == 0) __hip_atomic_store(&cv.ws->flag[member], (int)rebuild_flag[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             coop_publish();                    // positions (adam_phase), maxima, flag: complete before this member arrives
@@ -1135,10 +1161,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                     const float* xg = reinterpret_cast<const float*>(cv.ws->X + i);
                     X[i] = f32x4{coop_ld(xg), coop_ld(xg + 1), coop_ld(xg + 2), 1.f};
                 }
-            if (tid_s < OWN_WAVES) {                         // ... and their maxima (own waves: slots [0, OW), nothing here)
-                const bool mine = tid_s / OW == member;
-                dmaxbuf[np * MAX_WAVES + OWN_WAVES + tid_s] = mine ? 0.f : coop_ld(&cv.ws->scal[tid_s][0]);
-                movebuf[np * MAX_WAVES + OWN_WAVES + tid_s] = mine ? 0.f : coop_ld(&cv.ws->scal[tid_s][1]);
+            if (tid_s < S * OW && tid_s / OW != member) {     // ... and their owner waves' maxima (slot = owner wave of the cloud)
+                dmaxbuf[np * MAX_WAVES + tid_s] = coop_ld(&cv.ws->scal[tid_s][0]);
+                movebuf[np * MAX_WAVES + tid_s] = coop_ld(&cv.ws->scal[tid_s][1]);
             }
             if (tid_s >= 64 && tid_s < 64 + S && tid_s - 64 != member) {     // the other members' expiring certificates
                 const int nbad = __hip_atomic_load(&cv.ws->flag[tid_s - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1413,13 +1438,12 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
 #pragma unroll
         for (int a = 0; a < 3; ++a) {                         // the persistent kernel's adam_phase, term by term
             const float gn = (float)fi[a] * FIX32_INV;
-            const float gr = gn * rep_scale;
-            const float g = gocc[a] + gr;
+            const float g = __builtin_fmaf(gn, rep_scale, gocc[a]);
             float mr = m_io[o + a], vr = v_io[o + a];
-            mr = mr + (g - mr) * (1.f - 0.9f);
-            vr = vr * 0.999f + (1.f - 0.999f) * g * g;
+            mr = __builtin_fmaf(g - mr, 1.f - 0.9f, mr);
+            vr = __builtin_fmaf((1.f - 0.999f) * g, g, vr * 0.999f);
             const float denom = sqrtf(vr) / bc2 + 1e-8f;
-            xs[a] = xs[a] - step_size * (mr / denom);
+            xs[a] = __builtin_fmaf(-step_size, mr / denom, xs[a]);
             m_io[o + a] = mr;
             v_io[o + a] = vr;
             pc[3 * pt + a] = xs[a];
@@ -1588,9 +1612,21 @@ hipError_t launch_optimize(const float* dec_img, const float* planes, float* p, 
     }
     if (split == 1 || K < 256) return IFD_PART(1, 0, B);      // (tiny clouds: nothing to share out)
     const int full = (B / n_cu) * n_cu, rest = B - full;
-    if (rest == 0 || 2 * rest > n_cu) return IFD_PART(1, 0, B);      // (more than half a round: two split launches take as long as the one round)
+#ifndef IFD_MIXED_TAIL
+#define IFD_MIXED_TAIL 0
+#endif
+    // Measured per launch of n_cu / S clouds, in rounds of the unsplit kernel: S = 2 0.575, S = 4 0.365.  A rest
+    // between n_cu / 2 and 3 n_cu / 4 as n_cu / 2 clouds at S = 2 + the others at S = 4 adds up to 0.94 on paper; measured on
+    // the bench workload (2468 clouds: 9 rounds + 164) it is 820.4 ms against 812.6 with the rest as a tenth round - each
+    // launch's drain is exposed - so it is off.
+    const bool mixed = IFD_MIXED_TAIL && 2 * rest > n_cu && 4 * rest <= 3 * n_cu;
+    if (rest == 0 || (2 * rest > n_cu && !mixed)) return IFD_PART(1, 0, B);
     if (full > 0) e = IFD_PART(1, 0, full);
     if (e != hipSuccess) return e;
+    if (mixed) {
+        e = IFD_PART(2, full, n_cu / 2);
+        return e != hipSuccess ? e : IFD_PART(4, full + n_cu / 2, rest - n_cu / 2);
+    }
     return 4 * rest <= n_cu ? IFD_PART(4, full, rest) : IFD_PART(2, full, rest);
 #undef IFD_PART
 }
