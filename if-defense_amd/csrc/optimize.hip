@@ -1023,11 +1023,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #else
         KnnCounters cn{lcnt, lane};
 #endif
-        // Split clouds run the tiles FIRST and the owner waves' kNN phase at the end of the step: only 8 / S of a member's
-        // waves have neighbour duty, and a kNN wave beside a priority-1 tile wave is starved for a whole tile (measured: 100 k
-        // cycles for its 25 k of work) while that tile wave, without a partner that issues MFMAs, runs at little more than
-        // half the paired rate.  Measured at S = 2 / 4 (53 clouds x 501 steps, one S = 1 round: 84.7 ms): kNN first 52.0 /
-        // 36.0 ms, kNN first with the partner's first tile at the kNN wave's priority 55.7 / 34.8, tiles first 50.6 / 34.5.
+        // Split clouds: eight (S = 2) or four (S = 4) of a member's waves have neighbour duty, and a kNN wave beside a
+        // priority-1 tile wave is starved for a whole tile (measured: 100 k cycles for its 25 k of work), so the kNN phase runs
+        // FIRST at wave priority 2 (IFD_SPLIT_KNN_PRIO).  Measured at S = 2 / 4 (53 clouds x 501 steps, one S = 1 round:
+        // 83.1 ms): 47.7 / 30.3 ms; without the priority 48.1 / 32.3; tiles first, kNN at the end of the step 50.6 / 34.5.
+        // (S = 1, where every wave has neighbour duty: letting the upper four waves run one tile before their kNN phase, so
+        // that on every SIMD one wave searches while the other feeds the MFMA pipe, measured 912 ms against 807.6 on the
+        // bench launch at priority 2, 921 at equal priority, 973 with two tiles first - f32 MFMA and VALU share the issue
+        // cycles, a lone tile wave runs at about half the paired rate, and the phases side by side only lengthen both.)
         // ---- decoder tiles, pulled from an LDS counter until the step's tiles run out -----------------------------------
         auto run_tiles = [&]() __attribute__((always_inline)) {
 #pragma unroll 1
