@@ -16,12 +16,23 @@ constexpr int CLOUD_PLANE_FLOATS = 3 * PLANE_FLOATS; // 1.5 MiB / cloud
 
 // ---- decoder parameter image (identical in global memory and in LDS) -------------
 // W[15][32][34]: layer L = 3*i + j (j: 0 fc_c[i], 1 blocks[i].fc_0, 2 blocks[i].fc_1), row = out
-// channel o, column = wperm(in channel c), row stride 34 floats.  With the 16x16x4 MFMA operand mapping of
-// optimize.hip (lane = (n, q), A[m = n][k = q]) the forward A-operand gather W[16mt+n][16mt'+4q+r'] hits bank
-// (2n + q + const) mod 32 - conflict-free - and the transposed gather of the backward pass is 2-way at worst.
+// channel o, column = wperm(in channel c), row stride 34 floats.  The 16x16x4 MFMA operand mapping of optimize.hip
+// (lane = (n, q), A[m = n][k = q]) reads the A operands with ds_read(2)_b32: 32 banks, the lanes 0-31 (q = 0, 1) and
+// 32-63 (q = 2, 3) are served together.
+//   forward  gather W[16 mt + n][16 mt' + 4 q + r']:  bank (2 n + wperm(4 q) + const) mod 32 - wperm(4 q) = 0, 1, 16, 17:
+//            the two q of a group differ in parity, 2 n covers the even banks: conflict-free;
+//   backward gather W[16 mt' + 4 q + r'][16 mt + n]:  bank (8 q + wperm(n) + const) mod 32 - wperm maps the columns
+//            0-15 onto {0-7, 16-23} (16-31 onto {8-15, 24-31}), a set disjoint from itself shifted by 8: conflict-free.
+// (Rounds 1-2 kept the columns of a 16-block together, wperm(c) = (c & 16) + 4 (c & 3) + ((c >> 2) & 3): the backward gather
+// was then 2-way - banks 8 q + [0, 16) - and owned 72 % of the kernel's SQ_LDS_BANK_CONFLICT cycles, 488 per 32-point tile;
+// scripts/pmc_lds_attrib.sh.)
 constexpr int W_STRIDE = 34;
 constexpr int W_LAYER = 32 * W_STRIDE;               // 1088
+#ifdef IFD_WPERM_OLD
 __host__ __device__ constexpr int wperm(int c) { return (c & 16) + 4 * (c & 3) + ((c >> 2) & 3); }
+#else
+__host__ __device__ constexpr int wperm(int c) { return 8 * ((c >> 4) & 1) + ((c >> 2) & 1) + 2 * (c & 3) + 16 * ((c >> 3) & 1); }
+#endif
 constexpr int DEC_OFF_W = 0;
 constexpr int DEC_OFF_BIAS = 15 * W_LAYER;           // 16320: [15][32]
 constexpr int DEC_OFF_WP = DEC_OFF_BIAS + 15 * 32;   // [32][4] = {Wp[ch][0..2], bp[ch]}

@@ -41,22 +41,23 @@ struct Acc2 {
 // `lo` is the lane's offset into a layer (LaneOff below), made opaque once per tile so that the loop-invariant
 // LDS weight loads are not hoisted out of the tile loop by LICM (they would be spilled to scratch).
 struct LaneOff {
-    int fwd;    // n * S + q
-    int bwd;    // 4 q * S + wperm16(n)
+    int fwd;    // n * S + wperm(4 q)
+    int bwd;    // 4 q * S + wperm(n)
     int q4;     // 4 q
 };
 
 template <bool TRANSPOSED>
 __device__ __forceinline__ Acc2 dense32(const float* __restrict__ wl, const LaneOff& lo, const f32x8& in, Acc2 acc) {
-    // forward : A = W[16 mt + n][16 mt' + 4 q + r']  at  (16 mt + n) * S + 16 mt' + 4 r' + q
-    // backward: A = W[16 mt' + 4 q + r'][16 mt + n]  at  (16 mt' + 4 q + r') * S + 16 mt + wperm16(n)
+    // forward : A = W[16 mt + n][16 mt' + 4 q + r']  at  (16 mt + n) * S + wperm(16 mt' + r') + wperm(4 q)
+    // backward: A = W[16 mt' + 4 q + r'][16 mt + n]  at  (16 mt' + 4 q + r') * S + wperm(16 mt) + wperm(n)
+    // (wperm's bit fields are independent: wperm(a + b) = wperm(a) + wperm(b) for the index parts above)
     const float* base = wl + (TRANSPOSED ? lo.bwd : lo.fwd);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int mtp = s >> 2, rp = s & 3;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + 16 * mt) : (16 * mt * W_STRIDE + 16 * mtp + 4 * rp);
+            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + wperm(16 * mt)) : (16 * mt * W_STRIDE + wperm(16 * mtp + rp));
             acc.t[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(base[off], in[s], acc.t[mt], 0, 0, 0);
         }
     }
@@ -122,7 +123,7 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
                                              float thr, float inv_lb, float& logit_out, float& bce_out,
                                              float (&dx)[3]) {
     const int n = lane & 15, q = lane >> 4;
-    LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
+    LaneOff lo = {n * W_STRIDE + wperm(4 * q), 4 * q * W_STRIDE + wperm(n), 4 * q};
     asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
     float pix[3], live[3];
     pixel_coord(x0, dc, pix[0], live[0]);
@@ -425,7 +426,7 @@ __device__ __forceinline__ WFrag load_wfrag(const float* __restrict__ wl, const 
         const int mtp = s >> 2, rp = s & 3;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + 16 * mt) : (16 * mt * W_STRIDE + 16 * mtp + 4 * rp);
+            const int off = TRANSPOSED ? ((16 * mtp + rp) * W_STRIDE + wperm(16 * mt)) : (16 * mt * W_STRIDE + wperm(16 * mtp + rp));
             f.a[2 * s + mt] = base[off];
         }
     }
@@ -544,7 +545,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
                                               float (&bce)[2], float (&dx)[2][3]) {
     constexpr int TV = 1;
     const int n = lane & 15, q = lane >> 4;
-    LaneOff lo = {n * W_STRIDE + q, 4 * q * W_STRIDE + 4 * (n & 3) + (n >> 2), 4 * q};
+    LaneOff lo = {n * W_STRIDE + wperm(4 * q), 4 * q * W_STRIDE + wperm(n), 4 * q};
     asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
     constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
     // d pix / d x = (RES - 1) / 2 * 2 / sdiv as one constant (the reference multiplies and divides in sequence; the
