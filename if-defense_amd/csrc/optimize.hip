@@ -1001,6 +1001,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     __syncthreads();
 #endif
 
+#ifndef IFD_CARRY_KNNPT
+#define IFD_CARRY_KNNPT 1             // S = 1: the certificates stay in registers from the Adam phase into the next step's kNN phase
+#endif
+    constexpr bool CARRY = S == 1 && IFD_CARRY_KNNPT != 0;
+    KnnPt ka_c = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false}, kb_c = ka_c;
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
         const bool want_loss = last && loss_out != nullptr;
@@ -1069,10 +1074,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             if (S > 1 && IFD_SPLIT_KNN_PRIO == 2) asm volatile("s_setprio 2");
             if (S > 1 && IFD_SPLIT_KNN_PRIO == 3) asm volatile("s_setprio 3");
             float rep_loss_a, rep_loss_b;
-            KnnPt ka, kb;
-            const int z = opaque_zero();
-            unpark_knnpt(park, z, PARK_KNN, ka);
-            unpark_knnpt(park, z, PARK_KNN + 4, kb);
+            // (one workgroup per cloud: the Adam phase of the last step left the certificates in registers - no scratch round
+            // trip in front of the step's first dependent work)
+            KnnPt ka = ka_c, kb = kb_c;
+            if (!CARRY) {
+                const int z = opaque_zero();
+                unpark_knnpt(park, z, PARK_KNN, ka);
+                unpark_knnpt(park, z, PARK_KNN + 4, kb);
+            }
             TRACE_STAMP(24, "s_waitcnt vmcnt(0)");            // parked state back from scratch
             uint16_t* La = cloud_lists + (size_t)(pa & (MAXK - 1)) * LIST_M;
             uint16_t* Lb = cloud_lists + (size_t)(pb & (MAXK - 1)) * LIST_M;
@@ -1141,6 +1150,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         TRACE_STAMP(29, "s_waitcnt lgkmcnt(0)");              // PIX written
         if (owner) store_adam(MV, tid_s, ast);
         adam_displacement(K, pa, pb, member * OW + wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
+        if (CARRY) { ka_c = ka; kb_c = kb; }
         if (S == 1) {
             if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
             __syncthreads();
