@@ -10,3 +10,4 @@ bash scripts/run_prof.sh 2468 > gpurun_out/r03_prof.txt 2>&1
 IFD_WEIGHTS=trained bash scripts/run_prof.sh 512 > gpurun_out/r03_prof_trained.txt 2>&1
 python scripts/check_split.py 53 501 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_check_split.txt
 cut -c1-400 gpurun_out/r03_bench.json
+bash scripts/pmc_lds_attrib.sh > /dev/null 2>&1
