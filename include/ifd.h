@@ -182,7 +182,9 @@ typedef struct ifd_opt_params {
                              one per cloud in whole rounds of one cloud per CU, and the clouds of the last partial round
                              split over 2 or 4 CUs each when that fills the GPU (fewer clouds than CUs, e.g. one GPU's shard
                              of a file spread over 8 GPUs, would otherwise cost a whole round); 1 = never split; 2 / 4 =
-                             every cloud split (validation).  The results do not depend on it, bit for bit. */
+                             every cloud split (validation).  The results do not depend on it, bit for bit.  The
+                             members of a split cloud wait for each other on the GPU: do not run two processes with
+                             split launches on one GPU at the same time (set 1 there). */
     int32_t planes_shared;/* measurement only: != 0 makes every cloud read the planes of cloud 0 (the tap gathers then hit in
                              L2: scripts/ab_planes.py prices the gather traffic this way) */
 } ifd_opt_params;
