@@ -413,8 +413,8 @@ int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uin
             void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    if (!pc || !keep_mask || B < 1 || K < 2 || K > 4096 || k < 1 || k > 7 || k >= K)
-        return fail(ctx, IFD_ERR_ARG, "ifd_sor: bad argument (2 <= K <= 4096, 1 <= k <= 7)");
+    if (!pc || !keep_mask || B < 1 || K < 2 || K > PREP_MAXK || k < 1 || k > 7 || k >= K)
+        return fail(ctx, IFD_ERR_ARG, "ifd_sor: bad argument (2 <= K <= 10000, 1 <= k <= 7)");
     hipError_t e = launch_sor(pc, B, K, k, (double)alpha, keep_mask, value, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_sor launch", e);
 }
@@ -425,8 +425,8 @@ int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, 
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (!pc || !prm || prm->struct_size != (int32_t)sizeof(ifd_prep_params) || !sel || !t_per_cloud || !init_points ||
-        B < 1 || K < 1 || K > 4096 || prm->n_sel < 1 || prm->n_sel > 1024 || prm->n_opt < 1)
-        return fail(ctx, IFD_ERR_ARG, "ifd_prepare: bad argument (K <= 4096, n_sel <= 1024)");
+        B < 1 || K < 1 || K > PREP_MAXK || prm->n_sel < 1 || prm->n_sel > 1024 || prm->n_opt < 1)
+        return fail(ctx, IFD_ERR_ARG, "ifd_prepare: bad argument (K <= 10000, n_sel <= 1024)");
     PrepArgs a;
     a.cloud_base = (int)prm->cloud_index_base; a.n_sel = prm->n_sel; a.n_opt = prm->n_opt;
     a.padding_scale = prm->padding_scale; a.init_sigma = prm->init_sigma;

@@ -36,6 +36,7 @@ struct PrepArgs {
     float padding_scale, init_sigma;
     uint32_t seed_lo, seed_hi;
 };
+constexpr int PREP_MAXK = 10000;     // largest input cloud (points) of ifd_sor / ifd_prepare (prep.hip: LDS of prepare_kernel)
 hipError_t configure_prep_kernels();
 hipError_t launch_sor(const float* pc, int B, int K, int k_nn, double alpha, uint8_t* keep, double* value, hipStream_t s);
 hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, const PrepArgs& a, const int32_t* sel_idx,

@@ -13,8 +13,10 @@
 namespace ifd {
 
 constexpr int PREP_THREADS = 1024;
-constexpr int PREP_MAXK = 4096;          // largest input cloud (points) these kernels accept
-constexpr int PREP_PPT = PREP_MAXK / PREP_THREADS;   // points per thread: 4
+// PREP_MAXK (ifd_internal.h) = 10,000: the largest input cloud these kernels accept (the LDS of prepare_kernel: 16 bytes per
+// point).  Up to SOR_NARROW_MAXK points sor_kernel keeps the cloud in LDS in double (32 bytes per point); above, in float
+// with the doubles re-made per pair (12 bytes per point) - same values, see sor_kernel.
+constexpr int SOR_NARROW_MAXK = 4096;
 
 // ---- Philox-4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
@@ -59,36 +61,59 @@ __device__ __forceinline__ float block_minmax_f(float v, bool is_max, float* scr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// WIDE (K > SOR_NARROW_MAXK): the cloud sits in LDS as floats and every pair converts its candidate and squares it again.
+// The values are the same as the narrow layout's: a float converts to double exactly, a product of two such doubles is
+// exact (48 significant bits), so |x|^2 = (x x + y y) + z z has the same two roundings however it is contracted.
+template <bool WIDE>
 __global__ __launch_bounds__(PREP_THREADS) void sor_kernel(const float* __restrict__ pc, int K, int k_nn, double alpha,
                                                             uint8_t* __restrict__ keep, double* __restrict__ value_out) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
-    double* X = dsm;                      // [K][3]        (the launch sizes the LDS by K: 4 K + 16 doubles)
-    double* XX = X + 3 * K;               // [K]   |x|^2
-    double* scratch = XX + K;             // [16]
-    double val[PREP_PPT];                 // value of point tid + 1024 r (registers: the LDS would not hold a fifth array at 4096)
+    constexpr int PPT = WIDE ? (PREP_MAXK + PREP_THREADS - 1) / PREP_THREADS : SOR_NARROW_MAXK / PREP_THREADS;     // 10 : 4
+    double* scratch = dsm;                // [16]
+    double* X = dsm + 16;                 // narrow: [K][3] doubles, then XX [K] = |x|^2 (the launch sizes the LDS by K)
+    double* XX = X + 3 * K;
+    float* Xf = reinterpret_cast<float*>(dsm + 16);       // wide: [K][3] floats
+    double val[PPT];                      // value of point tid + 1024 r (registers)
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = pc + (size_t)b * K * 3;
     for (int i = tid; i < K; i += PREP_THREADS) {
-        const double x = (double)p[3 * i], y = (double)p[3 * i + 1], z = (double)p[3 * i + 2];
-        X[3 * i] = x; X[3 * i + 1] = y; X[3 * i + 2] = z;
-        XX[i] = x * x + y * y + z * z;
+        if (WIDE) {
+            Xf[3 * i] = p[3 * i]; Xf[3 * i + 1] = p[3 * i + 1]; Xf[3 * i + 2] = p[3 * i + 2];
+        } else {
+            const double x = (double)p[3 * i], y = (double)p[3 * i + 1], z = (double)p[3 * i + 2];
+            X[3 * i] = x; X[3 * i + 1] = y; X[3 * i + 2] = z;
+            XX[i] = x * x + y * y + z * z;
+        }
     }
     __syncthreads();
     double vsum = 0.0;
 #pragma unroll
-    for (int r = 0; r < PREP_PPT; ++r) {
+    for (int r = 0; r < PPT; ++r) {
         const int i = tid + r * PREP_THREADS;
         val[r] = 0.0;
         if (i >= K) continue;
-        const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2], xx = XX[i];
+        double x, y, z, xx;
+        if (WIDE) {
+            x = (double)Xf[3 * i]; y = (double)Xf[3 * i + 1]; z = (double)Xf[3 * i + 2];
+            xx = x * x + y * y + z * z;
+        } else {
+            x = X[3 * i]; y = X[3 * i + 1]; z = X[3 * i + 2]; xx = XX[i];
+        }
         // k_nn + 1 smallest of dist[i][j] = xx_j + (-2 x_i.x_j) + xx_i over ALL j (self included, as the reference);
         // k_nn <= 7
         double best[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) best[q] = INFINITY;
         for (int j = 0; j < K; ++j) {
-            const double inner = -2.0 * (x * X[3 * j] + y * X[3 * j + 1] + z * X[3 * j + 2]);
-            double d = (XX[j] + inner) + xx;
+            double xj, yj, zj, xxj;
+            if (WIDE) {
+                xj = (double)Xf[3 * j]; yj = (double)Xf[3 * j + 1]; zj = (double)Xf[3 * j + 2];
+                xxj = xj * xj + yj * yj + zj * zj;
+            } else {
+                xj = X[3 * j]; yj = X[3 * j + 1]; zj = X[3 * j + 2]; xxj = XX[j];
+            }
+            const double inner = -2.0 * (x * xj + y * yj + z * zj);
+            double d = (xxj + inner) + xx;
             if (d < best[7]) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -110,12 +135,12 @@ __global__ __launch_bounds__(PREP_THREADS) void sor_kernel(const float* __restri
     const double mean = block_sum_d(vsum, scratch) / (double)K;
     double sq = 0.0;
 #pragma unroll
-    for (int r = 0; r < PREP_PPT; ++r)
+    for (int r = 0; r < PPT; ++r)
         if (tid + r * PREP_THREADS < K) { const double d = val[r] - mean; sq += d * d; }
     const double var = block_sum_d(sq, scratch) / (double)(K - 1);       // torch.std: unbiased
     const double thr = mean + alpha * sqrt(var);
 #pragma unroll
-    for (int r = 0; r < PREP_PPT; ++r)
+    for (int r = 0; r < PPT; ++r)
         if (tid + r * PREP_THREADS < K) keep[(size_t)b * K + tid + r * PREP_THREADS] = val[r] <= thr ? 1 : 0;
 }
 
@@ -128,9 +153,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
                                                                 int32_t* __restrict__ n_kept, float* __restrict__ proc_out) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* P = fsm;                                                   // [K][3] kept points, then processed
-    uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * K);           // [K] random keys for the subset
-    int* POS = reinterpret_cast<int*>(KEY + K);                       // [K] compaction prefix
-    float* scratch = reinterpret_cast<float*>(POS + K + (K & 1));     // [64]  (8-byte aligned: holds doubles)
+    uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * K);           // [K] random keys for the subset ...
+    int* POS = reinterpret_cast<int*>(KEY);                           // ... in the place of the compaction prefix (done by then)
+    float* scratch = reinterpret_cast<float*>(KEY + K);               // [64]  (byte offset 16 K: 8-byte aligned, holds doubles)
     int* s_n = reinterpret_cast<int*>(scratch + 62);
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t gcloud = (uint32_t)(A.cloud_base + b);
@@ -236,20 +261,27 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
     }
 }
 
-// LDS by the cloud size: SOR 32 K + 128 B (131,200 B at K = 4096, 32,896 B at 1024), prepare 20 K + 260 B
-static size_t sor_lds(int K) { return ((size_t)4 * K + 16) * sizeof(double); }
-static size_t prep_lds(int K) { return (size_t)20 * K + 4 * (K & 1) + 64 * 4; }
+// LDS by the cloud size: SOR 32 K + 128 B up to 4096 points (131,200 B there, 32,896 B at 1024), 12 K + 128 B above
+// (120,128 B at 10,000); prepare 16 K + 256 B (160,256 B at 10,000)
+static size_t sor_lds(int K) { return K <= SOR_NARROW_MAXK ? ((size_t)4 * K + 16) * sizeof(double) : (size_t)12 * K + 4 * (K & 1) + 128; }
+static size_t prep_lds(int K) { return (size_t)16 * K + 64 * 4; }
 
 hipError_t configure_prep_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sor_lds(PREP_MAXK));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sor_lds(SOR_NARROW_MAXK));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sor_lds(PREP_MAXK));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)prep_lds(PREP_MAXK));
 }
 
 hipError_t launch_sor(const float* pc, int B, int K, int k_nn, double alpha, uint8_t* keep, double* value, hipStream_t s) {
-    hipLaunchKernelGGL(sor_kernel, dim3(B), dim3(PREP_THREADS), sor_lds(K), s, pc, K, k_nn, alpha, keep, value);
+    if (K <= SOR_NARROW_MAXK)
+        hipLaunchKernelGGL(sor_kernel<false>, dim3(B), dim3(PREP_THREADS), sor_lds(K), s, pc, K, k_nn, alpha, keep, value);
+    else
+        hipLaunchKernelGGL(sor_kernel<true>, dim3(B), dim3(PREP_THREADS), sor_lds(K), s, pc, K, k_nn, alpha, keep, value);
     return hipGetLastError();
 }
 

@@ -102,7 +102,7 @@ const char* ifd_last_error(const ifd_ctx* ctx);   /* ctx may be NULL: error of t
 
 /* sor_process / SORDefense.outlier_removal (ConvONet/opt_defense.py:86-111, defense/SOR.py:22-49):
  * pc [B,K,3] -> keep_mask [B,K] (1 = kept: value <= mean + alpha * std, float64 like the reference);
- * value (optional) [B,K] float64 = mean of the k nearest squared distances.  2 <= K <= 4096, k <= 7. */
+ * value (optional) [B,K] float64 = mean of the k nearest squared distances.  2 <= K <= 10000, k <= 7. */
 int ifd_sor(ifd_ctx* ctx, const float* pc, int B, int K, int k, float alpha, uint8_t* keep_mask,
             double* value, void* stream);
 
@@ -121,7 +121,7 @@ typedef struct ifd_prep_params {
  * (np.random.choice without replacement), init_idx [B,n_opt] (torch.randint), noise [B,n_opt,3] ~ N(0,1).
  * Outputs: sel [B,n_sel,3] (rows >= t_per_cloud[b] are zero), t_per_cloud [B] = min(n_kept, n_sel),
  * init_points [B,n_opt,3], n_kept (optional) [B], proc (optional) [B,K,3]: the processed kept points,
- * first n_kept[b] rows valid.  K <= 4096, n_sel <= 1024. */
+ * first n_kept[b] rows valid.  K <= 10000, n_sel <= 1024. */
 int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, int K, const ifd_prep_params* prm,
                 const int32_t* sel_idx, const int32_t* init_idx, const float* noise, float* sel,
                 int32_t* t_per_cloud, float* init_points, int32_t* n_kept, float* proc, void* stream);

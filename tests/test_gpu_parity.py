@@ -415,12 +415,44 @@ def test_sor_mask_bit_exact(restorer, golden):
 def test_sor_edge_sizes(restorer):
     from oracle import convonet_oracle as O
     g = torch.Generator().manual_seed(11)
-    for K in (8, 100, 1024, 1500, 2048, 3001, 4096):
-        pc = torch.randn(2, K, 3, generator=g)
-        ref, _ = O.sor_keep_mask(pc)
-        got = restorer.sor(pc).cpu().numpy().astype(bool)
+    for K in (8, 100, 1024, 1500, 2048, 3001, 4096, 4097, 6001, 10000):      # > 4096: the float-in-LDS layout of sor_kernel
+        pc = torch.randn(2 if K <= 4096 else 1, K, 3, generator=g)
+        ref, ref_val = O.sor_keep_mask(pc)
+        got, val = restorer.sor(pc, want_value=True)
+        got = got.cpu().numpy().astype(bool)
         print("SOR K=%d: mask mismatches %d of %d" % (K, (got != ref.numpy()).sum(), got.size))
         assert np.array_equal(got, ref.numpy()), K                   # boolean work on fp64 statistics: bit-exact
+        np.testing.assert_allclose(val.cpu().numpy(), ref_val.numpy(), rtol=1e-9, atol=1e-18)
+    with pytest.raises(Exception):                                   # the limit: 10,000 points (prepare_kernel's LDS)
+        restorer.sor(torch.zeros(1, 10001, 3))
+
+
+def test_prepare_large_input_clouds(restorer):
+    """10,000-point input clouds (the size of the resampled ModelNet40 clouds; the reference takes any size,
+    opt_defense.py:114-146): SOR mask, centring / scaling against the oracle's numpy restatement, a 600-subset without
+    replacement, init points that are cloud points + noise, and the encoder on the subset."""
+    from oracle import convonet_oracle as O
+    g = torch.Generator().manual_seed(21)
+    v = torch.randn(2, 10000, 3, generator=g)
+    pc = v / v.norm(dim=-1, keepdim=True) * (0.6 + 0.4 * torch.rand(2, 10000, 1, generator=g))
+    keep = restorer.sor(pc)
+    ref_keep, _ = O.sor_keep_mask(pc[:1])
+    assert np.array_equal(keep[:1].cpu().numpy().astype(bool), ref_keep.numpy())
+    out = restorer.prepare(pc, keep, seed=3, want_proc=True)
+    proc, sel, init = out["proc"].cpu().numpy(), out["sel"].cpu().numpy(), out["init"].cpu().numpy()
+    for b in range(2):
+        kept = pc[b][keep[b].cpu().bool()].numpy()
+        n = int(out["n_kept"][b])
+        assert n == len(kept) and 8000 < n < 10000
+        np.testing.assert_allclose(proc[b, :n], O.preprocess_pc(kept), rtol=0, atol=2e-7)
+        rows = {tuple(np.round(r, 6)) for r in proc[b, :n]}
+        got = [tuple(np.round(r, 6)) for r in sel[b]]
+        assert len(set(got)) == 600 and set(got) <= rows
+        d = torch.cdist(torch.from_numpy(init[b]), torch.from_numpy(proc[b, :n])).min(1).values
+        assert float(d.max()) < 0.08
+    assert out["t_per_cloud"].cpu().tolist() == [600, 600]
+    planes = restorer.encode_inputs(out["sel"], out["t_per_cloud"])
+    assert bool(torch.isfinite(planes).all())
 
 
 def test_prepare_with_recorded_draws(restorer, golden):

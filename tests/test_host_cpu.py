@@ -281,7 +281,7 @@ def test_cli_rejects_sizes_and_missing_files_before_loading_anything(tmp_path):
     ok = tmp_path / "ok.npz"
     np.savez(ok, test_pc=np.zeros((2, 64, 3), np.float32), test_label=np.zeros(2))
     big = tmp_path / "big.npz"
-    np.savez(big, test_pc=np.zeros((1, 4097, 3), np.float32), test_label=np.zeros(1))
+    np.savez(big, test_pc=np.zeros((1, 10001, 3), np.float32), test_label=np.zeros(1))
     nolabel = tmp_path / "nolabel.npz"
     np.savez(nolabel, test_pc=np.zeros((1, 64, 3), np.float32))
 
