@@ -495,9 +495,16 @@ int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float
                   void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    if (!p || !loss || bad_bk(B, K)) return fail(ctx, IFD_ERR_ARG, "ifd_repulsion: bad argument (6 <= K <= 4096)");
-    hipError_t e = K <= MAXK ? launch_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f, static_cast<hipStream_t>(stream))
-                             : launch_large_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f, static_cast<hipStream_t>(stream));
+    if (!p || !loss || bad_bk(B, K)) return fail(ctx, IFD_ERR_ARG, "ifd_repulsion: bad argument (6 <= K <= 10000)");
+    hipError_t e = hipSuccess;
+    if (K <= MAXK) {
+        e = launch_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f, static_cast<hipStream_t>(stream));
+    } else {
+        e = ensure_ws(ctx, large_f_bytes(B, K));          // (clouds beyond 4096 points: accumulators in the context's workspace)
+        if (e == hipSuccess)
+            e = launch_large_repulsion(p, B, K, loss, grad, knn_idx, 0.07f, 0.03f, 1e-12f, large_f_bytes(B, K) ? ctx->ws : nullptr,
+                                       static_cast<hipStream_t>(stream));
+    }
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_repulsion launch", e);
 }
 
@@ -507,7 +514,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: not a ConvONet context (use ifd_onet_optimize)");
     if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
-        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 4096)");
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 10000)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
@@ -554,7 +561,7 @@ int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    if (!p || B < 1 || K < 1 || K > LARGE_MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument (1 <= K <= 4096)");
+    if (!p || B < 1 || K < 1 || K > LARGE_MAXK) return fail(ctx, IFD_ERR_ARG, "ifd_normalize_unit_sphere: bad argument (1 <= K <= 10000)");
     hipError_t e = K <= MAXK ? launch_normalize(p, B, K, static_cast<hipStream_t>(stream))
                              : launch_large_normalize(p, B, K, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_normalize launch", e);
@@ -689,7 +696,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: not an ONet context");
     if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
-        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 4096)");
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 10000)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");

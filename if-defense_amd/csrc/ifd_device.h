@@ -41,7 +41,8 @@ constexpr int DEC_OFF_BOUT = DEC_OFF_WOUT + 32;      // [1] (+3 pad)
 constexpr int DEC_FLOATS = DEC_OFF_BOUT + 4;         // 16964 floats = 67,856 B
 
 constexpr int MAXK = 1024;           // points per cloud held in LDS (persistent optimiser kernel)
-constexpr int LARGE_MAXK = 4096;     // largest cloud of the launch-per-step path (optimize.hip, "large" section)
+constexpr int LARGE_MAXK = 10000;    // largest cloud of the launch-per-step path (optimize.hip, "large" section)
+constexpr int LARGE_LDS_MAXK = 4096; // ... up to here its repulsion accumulators sit in LDS, above in global memory
 constexpr int OPT_THREADS = 512;     // 8 waves: 2 per SIMD (256 VGPRs each), two points per thread
 constexpr float FIX_SCALE = 1099511627776.0f;        // 2^40: fixed-point scale of the neighbour scatter
 constexpr float FIX_INV = 1.0f / 1099511627776.0f;

@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Clouds of more than MAXK optimised points (--sample_npoint up to LARGE_MAXK = 4096)
+// Clouds of more than MAXK optimised points (--sample_npoint up to LARGE_MAXK = 10,000)
 // ---------------------------------------------------------------------------------------------
 // The persistent kernel keeps a cloud's whole optimiser state in one CU's LDS, which ends at 1024 points; the reference
 // has no such limit (opt_defense.py:27).  Larger clouds run the same arithmetic as two launches per Adam step:
@@ -1347,9 +1347,12 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 //   large_step_kernel        one workgroup per cloud: exact 5-NN by brute-force scan, repulsion terms into the same
 //                            fixed-point accumulators, Adam (moments in global memory), new points
 // The neighbour search is O(K^2) per step here (no certified lists) - a correct path for the rare large request, not a
-// tuned one: ~4x (K = 2048) to ~20x (K = 4096) the per-point cost of the persistent kernel.
+// tuned one: ~4x (K = 2048) to ~20x (K = 4096) the per-point cost of the persistent kernel.  Up to LARGE_LDS_MAXK = 4096
+// points the fixed-point repulsion accumulators sit in LDS next to the positions (28 bytes per point); above (GF = true) only
+// the positions do (16 bytes per point: 10,000 points fill the LDS) and the accumulators are integer atomics on a global
+// buffer of the workspace - the same integer sums.
 constexpr int LARGE_THREADS = 1024;
-constexpr int LARGE_PPT = LARGE_MAXK / LARGE_THREADS;      // points per thread: 4
+constexpr int LARGE_PPT = (LARGE_MAXK + LARGE_THREADS - 1) / LARGE_THREADS + ((LARGE_MAXK + LARGE_THREADS - 1) / LARGE_THREADS & 1);   // points per thread: 10 (even)
 
 __global__ __launch_bounds__(OPT_THREADS, 2) void large_occupancy_kernel(const float* __restrict__ dec_img,
                                                                           const float* __restrict__ planes,
@@ -1381,15 +1384,40 @@ struct LargeLds {
     RepAcc F;
     float* scratch;
 };
-__device__ __forceinline__ LargeLds large_lds(float* smem) {
+// f_ws (GF): [B][K] packed xy sums, then [B][K] z sums (large_f_bytes); zero on entry, left zero on exit
+template <bool GF>
+__device__ __forceinline__ LargeLds large_lds(float* smem, int K, int B, int cloud, void* f_ws) {
     LargeLds l;
-    l.X = reinterpret_cast<f32x4*>(smem);                                             // [LARGE_MAXK]
-    l.F.xy = reinterpret_cast<long long*>(l.X + LARGE_MAXK);                          // [LARGE_MAXK]
-    l.F.z = reinterpret_cast<int*>(l.F.xy + LARGE_MAXK);                              // [LARGE_MAXK]
-    l.scratch = reinterpret_cast<float*>(l.F.z + LARGE_MAXK);                         // [64]
+    l.X = reinterpret_cast<f32x4*>(smem);                                             // [LARGE_LDS_MAXK] / GF: [K]
+    if (GF) {
+        l.F.xy = static_cast<long long*>(f_ws) + (size_t)cloud * K;
+        l.F.z = reinterpret_cast<int*>(static_cast<long long*>(f_ws) + (size_t)B * K) + (size_t)cloud * K;
+        l.scratch = reinterpret_cast<float*>(l.X + K);                                // [64]
+    } else {
+        l.F.xy = reinterpret_cast<long long*>(l.X + LARGE_LDS_MAXK);                  // [LARGE_LDS_MAXK]
+        l.F.z = reinterpret_cast<int*>(l.F.xy + LARGE_LDS_MAXK);                      // [LARGE_LDS_MAXK]
+        l.scratch = reinterpret_cast<float*>(l.F.z + LARGE_LDS_MAXK);                 // [64]
+    }
     return l;
 }
-constexpr size_t LARGE_LDS = (size_t)LARGE_MAXK * (16 + 8 + 4) + 64 * 4;              // 114,944 B
+constexpr size_t LARGE_LDS = (size_t)LARGE_LDS_MAXK * (16 + 8 + 4) + 64 * 4;          // 114,944 B
+static size_t large_lds_bytes(int K) { return K <= LARGE_LDS_MAXK ? LARGE_LDS : (size_t)K * 16 + 64 * 4; }     // 160,256 B at 10,000
+size_t large_f_bytes(int B, int K) { return K <= LARGE_LDS_MAXK ? 0 : (size_t)B * K * 12; }
+// what a point received (GF: read past the L1 - the sums were made by atomics in the L2 - and cleared for the next step)
+template <bool GF>
+__device__ __forceinline__ void large_take_f(const RepAcc F, int pt, int (&fi)[3]) {
+    if (GF) {
+        const long long fxy = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(F.xy + pt), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+        fi[2] = __hip_atomic_load(F.z + pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unpack_xy(fxy, fi[0], fi[1]);
+        F.xy[pt] = 0;
+        F.z[pt] = 0;
+    } else {
+        unpack_xy(F.xy[pt], fi[0], fi[1]);
+        fi[2] = F.z[pt];
+    }
+}
 
 // exact 5-NN + repulsion terms of the points of this thread, two at a time (the persistent kernel's rep_point2)
 __device__ __forceinline__ void large_knn_rep(const LargeLds& l, int K, const RepConst rc, float (&rep_l)[LARGE_PPT],
@@ -1412,25 +1440,27 @@ __device__ __forceinline__ void large_knn_rep(const LargeLds& l, int K, const Re
     }
 }
 
+template <bool GF>
 __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __restrict__ p, float* __restrict__ m_io,
                                                                     float* __restrict__ v_io, const f32x4* __restrict__ G,
                                                                     int K, const float* __restrict__ adam_tab, int step,
                                                                     const int32_t* __restrict__ loss_batch_per_cloud,
                                                                     int loss_batch, float rep_weight, RepConst rc,
-                                                                    float* __restrict__ loss_out) {
+                                                                    float* __restrict__ loss_out, void* f_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const LargeLds l = large_lds(smem);
     const int cloud = blockIdx.x, tid = threadIdx.x;
+    const LargeLds l = large_lds<GF>(smem, K, (int)gridDim.x, cloud, f_ws);
     float* pc = p + (size_t)cloud * K * 3;
 #pragma unroll
     for (int r = 0; r < LARGE_PPT; ++r) {
         const int pt = tid + r * LARGE_THREADS;
         if (pt < K) l.X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
-        l.F.xy[pt] = 0;
-        l.F.z[pt] = 0;
+        if (!GF && pt < LARGE_LDS_MAXK) { l.F.xy[pt] = 0; l.F.z[pt] = 0; }
     }
     __syncthreads();
-    float rep_l[LARGE_PPT] = {0.f, 0.f, 0.f, 0.f};
+    float rep_l[LARGE_PPT];
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) rep_l[r] = 0.f;
     if (rep_weight > 0.f) large_knn_rep(l, K, rc, rep_l, nullptr);
     __syncthreads();
     const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
@@ -1446,8 +1476,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
         const float gocc[3] = {go.x, go.y, go.z};
         float xs[3] = {x.x, x.y, x.z};
         int fi[3];
-        unpack_xy(l.F.xy[pt], fi[0], fi[1]);
-        fi[2] = l.F.z[pt];
+        large_take_f<GF>(l.F, pt, fi);
         const size_t o = ((size_t)cloud * K + pt) * 3;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {                         // the persistent kernel's adam_phase, term by term
@@ -1473,24 +1502,30 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
 }
 
 // repulsion_loss(p) for K > MAXK (ifd_repulsion): loss [B], optional gradient and neighbour indices
+template <bool GF>
 __global__ __launch_bounds__(LARGE_THREADS) void large_repulsion_kernel(const float* __restrict__ p, int K,
                                                                          float* __restrict__ loss, float* __restrict__ grad,
-                                                                         int32_t* __restrict__ knn_idx, RepConst rc) {
+                                                                         int32_t* __restrict__ knn_idx, RepConst rc, void* f_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const LargeLds l = large_lds(smem);
     const int cloud = blockIdx.x, tid = threadIdx.x;
+    const LargeLds l = large_lds<GF>(smem, K, (int)gridDim.x, cloud, f_ws);
     const float* pc = p + (size_t)cloud * K * 3;
 #pragma unroll
     for (int r = 0; r < LARGE_PPT; ++r) {
         const int pt = tid + r * LARGE_THREADS;
         if (pt < K) l.X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
-        l.F.xy[pt] = 0;
-        l.F.z[pt] = 0;
+        if (!GF && pt < LARGE_LDS_MAXK) { l.F.xy[pt] = 0; l.F.z[pt] = 0; }
     }
     __syncthreads();
-    float rep_l[LARGE_PPT] = {0.f, 0.f, 0.f, 0.f};
+    float rep_l[LARGE_PPT];
+#pragma unroll
+    for (int r = 0; r < LARGE_PPT; ++r) rep_l[r] = 0.f;
     large_knn_rep(l, K, rc, rep_l, knn_idx ? knn_idx + (size_t)cloud * K * 5 : nullptr);
-    const float tot = block_sum(rep_l[0] + rep_l[1] + rep_l[2] + rep_l[3], l.scratch);     // (barriers inside: F complete)
+    // (the thread's terms added in the order r = 0, 1, 2, ...: the four-point sum of the <= 4096-point layout is a prefix)
+    float mine = rep_l[0];
+#pragma unroll
+    for (int r = 1; r < LARGE_PPT; ++r) mine += rep_l[r];
+    const float tot = block_sum(mine, l.scratch);                                            // (barriers inside: F complete)
     if (tid == 0) loss[cloud] = tot / ((float)K * 5.f);
     if (grad != nullptr) {
         const float sc = 1.f / ((float)K * 5.f);
@@ -1499,8 +1534,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_repulsion_kernel(const fl
             const int pt = tid + r * LARGE_THREADS;
             if (pt >= K) continue;
             int fi[3];
-            unpack_xy(l.F.xy[pt], fi[0], fi[1]);
-            fi[2] = l.F.z[pt];
+            large_take_f<GF>(l.F, pt, fi);
 #pragma unroll
             for (int a = 0; a < 3; ++a) grad[((size_t)cloud * K + pt) * 3 + a] = (float)fi[a] * FIX32_INV * sc;
         }
@@ -1575,11 +1609,17 @@ hipError_t configure_optimize_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_occupancy_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_step_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_step_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_repulsion_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_step_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)large_lds_bytes(LARGE_MAXK));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_repulsion_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_repulsion_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)large_lds_bytes(LARGE_MAXK));
     return e;
 }
 
@@ -1677,14 +1717,36 @@ hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* gr
 }
 
 size_t large_ws_bytes(int B, int K, bool own_moments) {
-    return (size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0);
+    return (size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0) + large_f_bytes(B, K);
+}
+// the repulsion accumulators of clouds beyond LARGE_LDS_MAXK points: the LAST large_f_bytes of the workspace, zeroed here
+// (every step leaves them zero again)
+hipError_t large_f_prepare(void* ws, int B, int K, bool own_moments, void** f_ws, hipStream_t s) {
+    *f_ws = nullptr;
+    if (K <= LARGE_LDS_MAXK) return hipSuccess;
+    *f_ws = static_cast<char*>(ws) + (size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0);
+    return hipMemsetAsync(*f_ws, 0, large_f_bytes(B, K), s);
+}
+static void large_step_launch(float* p, float* m, float* v, const f32x4* G, int B, int K, const float* adam_tab, int step,
+                              const int32_t* lbpc, const OptArgs& a, const RepConst& rc, float* loss, void* f_ws, hipStream_t s) {
+    if (K <= LARGE_LDS_MAXK)
+        hipLaunchKernelGGL(large_step_kernel<false>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, m, v, G, K, adam_tab,
+                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws);
+    else
+        hipLaunchKernelGGL(large_step_kernel<true>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, m, v, G, K, adam_tab,
+                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws);
 }
 
-// ws: [B][K] f32x4 occupancy gradients, then (m == nullptr) the two moment arrays, zeroed here
+// ws: [B][K] f32x4 occupancy gradients, then (m == nullptr) the two moment arrays, zeroed here, then large_f_bytes
 hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
                                  const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B, int K,
                                  const OptArgs& a, hipStream_t s) {
     f32x4* G = static_cast<f32x4*>(ws);
+    void* f_ws = nullptr;
+    {
+        hipError_t e = large_f_prepare(ws, B, K, m == nullptr, &f_ws, s);
+        if (e != hipSuccess) return e;
+    }
     if (m == nullptr) {
         m = reinterpret_cast<float*>(G + (size_t)B * K);
         v = m + (size_t)B * K * 3;
@@ -1697,9 +1759,8 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
     for (int step = 0; step < a.steps; ++step) {
         hipLaunchKernelGGL(large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
                            loss_batch_per_cloud, a.loss_batch, a.threshold, G, a.dc);
-        hipLaunchKernelGGL(large_step_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LDS, s, p, m, v, G, K, adam_tab, step,
-                           loss_batch_per_cloud, a.loss_batch, a.rep_weight, rc,
-                           (step == a.steps - 1) ? loss : nullptr);
+        large_step_launch(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a, rc, (step == a.steps - 1) ? loss : nullptr,
+                          f_ws, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1709,18 +1770,27 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
 
 // One Adam step of the large-cloud path for any decoder (ConvONet above, ONet in onet.hip): G holds the occupancy gradient
 // of every point (f32x4: d loss / d xyz, BCE term), large_step_kernel does the exact 5-NN, the repulsion terms and Adam.
+// f_ws: large_f_prepare's pointer (nullptr up to LARGE_LDS_MAXK points)
 hipError_t launch_large_step(float* p, float* m, float* v, const void* G, int B, int K, const float* adam_tab, int step,
-                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, hipStream_t s) {
+                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws, hipStream_t s) {
     const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
-    hipLaunchKernelGGL(large_step_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LDS, s, p, m, v, static_cast<const f32x4*>(G), K,
-                       adam_tab, step, loss_batch_per_cloud, a.loss_batch, a.rep_weight, rc, loss);
+    large_step_launch(p, m, v, static_cast<const f32x4*>(G), B, K, adam_tab, step, loss_batch_per_cloud, a, rc, loss, f_ws, s);
     return hipGetLastError();
 }
 
+// f_ws: large_f_bytes(B, K) of scratch (any content; nullptr up to LARGE_LDS_MAXK points)
 hipError_t launch_large_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
-                                  float h, float eps, hipStream_t s) {
+                                  float h, float eps, void* f_ws, hipStream_t s) {
     RepConst rc = {radius, h, eps};
-    hipLaunchKernelGGL(large_repulsion_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LDS, s, p, K, loss, grad, knn_idx, rc);
+    if (K <= LARGE_LDS_MAXK) {
+        hipLaunchKernelGGL(large_repulsion_kernel<false>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, K, loss, grad,
+                           knn_idx, rc, nullptr);
+    } else {
+        hipError_t e = hipMemsetAsync(f_ws, 0, large_f_bytes(B, K), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(large_repulsion_kernel<true>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, K, loss, grad,
+                           knn_idx, rc, f_ws);
+    }
     return hipGetLastError();
 }
 

@@ -127,7 +127,7 @@ def check_supported(cfg, model="convonet"):
 
 
 # Sizes the kernels hold in LDS (include/ifd.h): more than the reference's Python needs, but finite.
-MAX_SAMPLE_NPOINT = {"convonet": 4096, "onet": 4096}   # optimised points per cloud (> 1024 takes the two-launch-per-step path)
+MAX_SAMPLE_NPOINT = {"convonet": 10000, "onet": 10000}   # optimised points per cloud (> 1024 takes the two-launch-per-step path)
 MAX_INPUT_POINTS = 10000      # points per input cloud (SOR / preprocess: ifd_internal.h PREP_MAXK)
 MAX_ENCODER_POINTS = 1024     # data.pointcloud_n, the encoder subset
 

@@ -197,7 +197,7 @@ typedef struct ifd_opt_params {
  * pre-update points (what the reference prints at :229-236, before 1/B and weights).
  * loss_batch_per_cloud (optional) [B] int32: overrides prm->loss_batch per cloud, so clouds that belong to
  * different reference batches (the last batch of a file is shorter) can share one launch.
- * 6 <= K <= 4096.  Up to 1024 points a cloud runs in the persistent one-launch kernel; 1025 ... 4096 points take two
+ * 6 <= K <= 10000.  Up to 1024 points a cloud runs in the persistent one-launch kernel; 1025 ... 10000 points take two
  * launches per Adam step (decoder gradient; exact brute-force 5-NN + repulsion + Adam), same arithmetic, and
  * knn_scan_every_step / the counters below do not apply. */
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,

@@ -288,7 +288,7 @@ def test_cli_rejects_sizes_and_missing_files_before_loading_anything(tmp_path):
     def boom(cfg, device):                                          # validation must come first: the model is never built
         raise AssertionError("the model was built before the arguments were validated")
 
-    for argv, word in ((["--data_root", str(ok), "--sample_npoint", "4097"], "sample_npoint"),
+    for argv, word in ((["--data_root", str(ok), "--sample_npoint", "10001"], "sample_npoint"),
                        (["--data_root", str(big)], "points per cloud"),
                        (["--data_root", str(nolabel)], "test_label"),
                        (["--data_root", str(tmp_path / "missing.npz")], "not found"),
