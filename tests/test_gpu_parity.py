@@ -720,15 +720,15 @@ def test_cli_end_to_end(tmp_path, np_weights):
 
 
 def test_cli_large_inputs_and_sample_npoint_2048(tmp_path, np_weights):
-    """The reference takes any size (opt_defense.py:27, SOR.py:22-49); this build up to 4096 points per input cloud and
-    4096 optimised points: 3000-point inputs through SOR / preprocess / encoder, 2048 points optimised on the
-    two-launch-per-step path, the reference's output contract."""
+    """The reference takes any size (opt_defense.py:27, SOR.py:22-49); this build up to 10,000 points per input cloud and
+    10,000 optimised points: 5000-point inputs through SOR (its float-in-LDS layout) / preprocess / encoder, 2048 points
+    optimised on the two-launch-per-step path, the reference's output contract."""
     import subprocess, sys, os
     wpath = tmp_path / "convonet.pth"
     torch.save({k: torch.from_numpy(v) for k, v in np_weights.items()}, wpath)
     rng = np.random.default_rng(0)
-    v = rng.normal(size=(3, 3000, 3)).astype(np.float32)
-    pc = (v / np.linalg.norm(v, axis=-1, keepdims=True) * rng.uniform(0.5, 1.0, size=(3, 3000, 1))).astype(np.float32)
+    v = rng.normal(size=(3, 5000, 3)).astype(np.float32)
+    pc = (v / np.linalg.norm(v, axis=-1, keepdims=True) * rng.uniform(0.5, 1.0, size=(3, 5000, 1))).astype(np.float32)
     src = tmp_path / "big.npz"
     np.savez(src, test_pc=pc, test_label=np.arange(3))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
