@@ -56,6 +56,7 @@ constexpr int ONET_NCBN = 11;        // bn_0 / bn_1 of 5 blocks + the final bn
 // x + (x of lane ^ 16) and x + (x of lane ^ 32) through gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap:
 // one vector instruction, no LDS crossbar round trip like the ds_bpermute behind __shfl_xor).  Same pairs, and the float
 // sum commutes: bit-identical to the shuffle form.
+// [pcsamp:tile.lane_reduce]
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float add_lane_xor16(float x) {
     const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);

@@ -12,6 +12,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // 5-NN + repulsion
 // ---------------------------------------------------------------------------------------------
+// [pcsamp:knn.scan]
 struct Top5 {
     float d0, d1, d2, d3, d4;
     int i0, i1, i2, i3, i4;
@@ -127,6 +128,7 @@ enum { PC_BUILD = 0, PC_EVAL, PC_REP, PC_TILES, PC_WAIT, PC_ADAM, PC_T, PC_KNN0,
 #define pc_wait PC_WAIT
 #define pc_adam PC_ADAM
 
+// [pcsamp:knn.exact_lists]
 // 5 nearest of points ia / ib among entries [E0, E1) of their lists, continuing the running top-5 in ta / tb.
 // The two independent insertion chains are interleaved for ILP.  Entries >= cnt are ignored.
 template <int E0, int E1>
@@ -174,6 +176,7 @@ __device__ __forceinline__ void list_top5_2(const f32x4* __restrict__ X, const u
     }
 }
 
+// [pcsamp:knn.keys]
 // ---- fast evaluation: 32-bit keys = (distance bits with the low 10 mantissa bits replaced by the index) --------
 // Positive floats order like their bit patterns, so a running sorted top-6 of keys needs one v_min_u32 and five
 // v_med3_u32 per entry - no compare masks, no index selects (16 instead of ~33 VALU ops per entry).  The 5 smallest
@@ -263,6 +266,7 @@ struct KnnPt {
     bool pend;          // individual refresh requested for the next step
 };
 
+// [pcsamp:knn.build]
 // One target of the wave-cooperative ("transposed") list build: the lanes hold the K candidate points in registers
 // (16 each).  Every lane first collects its hits as two 16-bit masks (front ball / ring), the list positions come from
 // wave prefix sums of the hit counts, and each lane then stores its (typically 0-2) hits - ~250 instructions per
@@ -324,6 +328,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// [pcsamp:knn.refresh]
 // (Re)build the lists of the flagged points of this wave (need_a / need_b per lane; d4a / d4b: upper bounds of their
 // squared 5-NN distances at the current positions).  Targets are taken one at a time off the ballot mask, so the
 // cost is ~1 us for loading the candidates plus ~0.5 us per target - whole-cloud rebuilds (all flagged) and the
@@ -404,6 +409,7 @@ __device__ __forceinline__ void knn_refresh(const f32x4* __restrict__ X, int K, 
     }
 }
 
+// [pcsamp:knn.resolve]
 // (distance, index)-lexicographic minimum over the wave, in every lane: DPP inside the rows of 16 (xor 1, xor 2, the two
 // mirrors), then the row / half swaps of gfx950 - twelve vector instructions instead of twelve ds_bpermute round trips
 // (__shfl_xor) per call; knn_resolve_failures calls it five times per target and the whole workgroup waits for the
@@ -501,6 +507,7 @@ __device__ __forceinline__ void knn_resolve_failures(const f32x4* __restrict__ X
     }
 }
 
+// [pcsamp:rep.standalone]
 struct RepConst {
     float radius, h, eps;
 };
@@ -579,6 +586,7 @@ __device__ __forceinline__ void unpack_xy(long long s, int& x, int& y) {
 // the data with agent-scope loads.  (A formal agent-scope release / acquire pair adds an L2 write-back of everything the
 // XCD has dirtied - the parked scratch state of 32 workgroups - and an invalidate: 35 us per step, measured.)
 // ---------------------------------------------------------------------------------------------
+// [pcsamp:coop]
 constexpr int MAX_COOP_WAVES = 16;    // owner waves of a split cloud: S members x (8 at S = 2, 4 at S = 4) = MAX_WAVES
 struct CoopWs {
     f32x4 X[MAXK];                    // positions after the last Adam step (written by the owners)
@@ -636,6 +644,7 @@ __device__ __forceinline__ void coop_flush_remote(const RepAcc F, const CoopView
     }
 }
 
+// [pcsamp:knn.rep_terms]
 // The two owned points together (optimiser): one instruction stream with the two independent chains interleaved -
 // two rep_point calls under separate `if (p < K)` branches cannot overlap their LDS / sqrt / exp / divide latencies.
 // The centre's own share (minus what its five neighbours receive) goes into F with the same fixed-point atomics: integer
@@ -715,6 +724,7 @@ __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const Re
 // ---------------------------------------------------------------------------------------------
 // block helpers
 // ---------------------------------------------------------------------------------------------
+// [pcsamp:block_helpers]
 constexpr int OWN_WAVES = OPT_THREADS / 64;   // waves whose threads own points (kNN / Adam duty): threads [0, 512)
 constexpr int MAX_WAVES = 16;
 
@@ -779,6 +789,7 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
 }
 
 
+// [pcsamp:knn.phase]
 // Block-shared scalars of the neighbour-list protocol (LDS).
 struct KnnShared {
     float* dmaxbuf;                  // [2][MAX_WAVES] per-wave max displacement from the epoch reference (next step)
@@ -961,6 +972,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
     PROF_ACC(pc_rep);
 }
 
+// [pcsamp:adam.update]
 // Adam state of the two owned points (torch.optim.Adam keeps exp_avg / exp_avg_sq per coordinate).
 struct AdamState {
     float mm[6], vv[6];
@@ -1032,6 +1044,7 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
     mv2_out = mv2;
 }
 
+// [pcsamp:adam.displacement]
 // Second half of the Adam phase: this wave's displacement / step-length maxima for the neighbour-list certificates of
 // the next step.  It is the only part that needs the parked per-point state (x0, dbase: a scratch round trip issued just
 // before the mid-step barrier), so it runs LAST - after the update, the sampling coordinates and the moments - and the
@@ -1068,6 +1081,7 @@ __device__ __forceinline__ void adam_displacement(int K, int pa, int pb, int wav
 // 128-byte one into a register vector with dynamic indexing (3,000 spilled registers, 4x the step time), and a volatile
 // one into uncached flat accesses.
 // ---------------------------------------------------------------------------------------------
+// [pcsamp:park]
 __device__ __forceinline__ int opaque_zero() {
     int z;
     asm volatile("v_mov_b32 %0, 0" : "=v"(z) : : "memory");
@@ -1090,6 +1104,7 @@ __device__ __forceinline__ void unpark_knnpt(const f32x4* park, int z, int base,
     k.frag = (fl & 1) != 0;
     k.pend = (fl & 2) != 0;
 }
+// [pcsamp:adam.moments]
 // The Adam moments of the owner threads sleep in LDS between Adam phases: mv[3][OPT_THREADS] float4, slot k of thread
 // t at mv[k * OPT_THREADS + t] (conflict-free 16-byte accesses).
 __device__ __forceinline__ void store_adam(f32x4* mv, int t, const AdamState& st) {

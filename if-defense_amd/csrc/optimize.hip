@@ -32,6 +32,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
+// [pcsamp:standalone_tile]
 struct Acc2 {
     f32x4 t[2];     // M-tile 0 (channels 4q..4q+3) and M-tile 1 (channels 16+4q..)
 };
@@ -91,6 +92,7 @@ __device__ __forceinline__ uint32_t mask_pos(const f32x8& v) {
 // ReLU as an integer max on the float bits: one v_max_i32 instead of hipcc's canonicalise + v_max_f32 pair
 // (negative floats, -0.0 included, are negative integers; positive floats keep their bits; MFMA never yields NaN
 // from finite inputs here).
+// [pcsamp:tile.relu]
 __device__ __forceinline__ f32x8 relu8(const f32x8& v) {
     f32x8 o;
 #pragma unroll
@@ -98,6 +100,7 @@ __device__ __forceinline__ f32x8 relu8(const f32x8& v) {
     return o;
 }
 
+// [pcsamp:standalone_tile]
 // common.py:250-257 then grid_sample's unnormalise (align_corners) + border clip.
 __device__ __forceinline__ void pixel_coord(float xa, const DecConst& dc, float& pix, float& live) {
     float u = xa / dc.sdiv + 0.5f;
@@ -359,6 +362,7 @@ __device__ __forceinline__ void decoder_tile(const float* __restrict__ W, const 
 // a zero bias under an all-dead input, sits under a dead outer mask).  Integer / bit-field / SDWA instructions cost ~6
 // SIMD cycles each next to the f32 MFMAs (scripts/valu_rates.hip): round 1's exact-at-+0 form (v_max, v_add -1,
 // v_alignbit | v_bfe, v_bfi) was 29 cycles per value, bit masks through v_alignbit | v_bfe + v_and 24, this one 20.
+// [pcsamp:tile.mask_pack]
 struct Mask8 {
     uint32_t w[2];
 };
@@ -413,6 +417,7 @@ __device__ __forceinline__ Mask8 mask_alive_packed(const f32x8& v, const f32x8& 
 // overlaps what is adjacent in its instruction stream, hence the explicit sched_group_barrier interleave
 // (1 MFMA : n VALU : m DS-read) inside every region and a sched_barrier between regions.
 // ---------------------------------------------------------------------------------------------
+// [pcsamp:tile.wfrag_lds]
 struct WFrag {
     float a[16];    // a[2 * s + mt]
 };
@@ -433,6 +438,7 @@ __device__ __forceinline__ WFrag load_wfrag(const float* __restrict__ wl, const 
     return f;
 }
 
+// [pcsamp:tile.mfma]
 __device__ __forceinline__ void mfma16(const WFrag& f, const f32x8& in, Acc2& acc) {
 #pragma unroll
     for (int s = 0; s < 8; ++s)
@@ -456,6 +462,7 @@ __device__ __forceinline__ void region_end() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// [pcsamp:tile.acc_add]
 // four v_pk_add_f32 instead of eight v_add_f32 (the accumulator quads are register pairs)
 __device__ __forceinline__ f32x4 add4_pk(const f32x4& a, const f32x4& b) {
     const f32x2 lo = f32x2{a.x, a.y} + f32x2{b.x, b.y};
@@ -482,6 +489,7 @@ __device__ __forceinline__ Acc2 acc_zero() {
     r.t[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     return r;
 }
+// [pcsamp:tile.mask_apply]
 // z & (sign-extended mask byte): written so that hipcc's SDWA peephole folds the byte extraction into the v_and
 // (v_and_b32_sdwa ... src0_sel:BYTE_k with sext) - one instruction per value, and the compiler keeps track of the
 // MFMA -> VALU hazard of z itself.
@@ -500,6 +508,7 @@ __device__ __forceinline__ f32x8 masked(const f32x8& z, const Mask8& m) {
 }
 __device__ __forceinline__ f32x8 masked(const Acc2& z, const Mask8& m) { return masked(flat(z), m); }
 
+// [pcsamp:adam.pix]
 // ---- sampling coordinates, once per point and step ---------------------------------------------------------------
 // The owner thread of a point turns its coordinates into the three pixel coordinates of grid_sample (pixel_coord above:
 // normalize_coordinate's divide / clamp, align_corners un-normalisation, border clip) when it writes the point - at
@@ -518,6 +527,7 @@ __device__ __forceinline__ f32x4 pix_encode(float x0, float x1, float x2, const 
     return o;
 }
 
+// [pcsamp:tile.geometry]
 struct SubGeo {                      // per-point sampling geometry of one sub-tile lane
     float w0[3], w1[3], lk[3];       // bilinear weights per axis; d pix / d x (0 for a clamped coordinate)
     int cell[3];
@@ -536,6 +546,7 @@ __device__ __forceinline__ void sub_geometry(SubGeo& g, const f32x4 pp, float ks
     }
 }
 
+// [pcsamp:tile.setup]
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 template <int MODE>
@@ -576,6 +587,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #pragma unroll
         for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
     const int q16 = 16 * q;
+// [pcsamp:tile.tap_loads]
     auto load_taps = [&](int P, f32x4 (&tap)[2][4][2], bool opaque) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -595,6 +607,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             }
         }
     };
+// [pcsamp:tile.sample_fwd]
     auto sample_fwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -633,6 +646,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         }
     };
     {
+// [pcsamp:tile.gather_seq]
         f32x4 tap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
         load_taps(0, tap0, false);
         load_taps(1, tap1, false);
@@ -646,6 +660,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         __builtin_amdgcn_sched_barrier(0);
     }
 
+// [pcsamp:tile.fc_p]
     // Wave priority: 1 while the wave streams MFMAs, 0 in its VALU / memory sections (and in the kNN / Adam phases).  An
     // f32 MFMA and a vector instruction cannot overlap on a SIMD and every switch between the two costs issue cycles
     // (scripts/mfma_valu_inwave.hip); with the MFMA wave preferred its stream runs back to back and the partner's vector
@@ -668,6 +683,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     WFrag A = load_wfrag<false>(Wd, lo);         // weights of the first layer (after the gather: its registers are free now)
     __builtin_amdgcn_sched_barrier(0);
 
+// [pcsamp:tile.fwd_mlp]
     // ---- forward MLP, software pipelined ---------------------------------------------------------------------
     Mask8 mask_a[2][NBLK], mask_h[2][NBLK];
     f32x8 wout;
@@ -726,6 +742,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         net[1] = o1;
         region_end<0, 1>();
     }
+// [pcsamp:tile.logit]
     f32x8 dn[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -763,6 +780,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     }
     __builtin_amdgcn_sched_barrier(0);
 
+// [pcsamp:tile.bwd_mlp]
     // ---- backward, software pipelined (A holds fc_1[4]^T) ----------------------------------------------------------
     Acc2 dcc[2] = {acc_zero(), acc_zero()};
 #pragma unroll
@@ -799,6 +817,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         region_end<0, 1>();
     }
     asm volatile("s_setprio 0");
+// [pcsamp:tile.fc_p_bwd]
     float g[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
@@ -816,6 +835,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     // d c / d u through the bilinear taps (grid_sampler_2d backward w.r.t. the grid), taps re-gathered
     f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
     // packed along the channels (even / odd partial sums, added at the end): register pairs as loaded, no shuffling
+// [pcsamp:tile.sample_bwd]
     auto sample_bwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -846,6 +866,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         }
     };
     {
+// [pcsamp:tile.bwd_gather_seq]
         // two planes in flight (three spill here, and starting the re-gather under the last MLP block does too:
         // both measured slower)
         f32x4 btap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
@@ -870,6 +891,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     asm volatile("s_setprio 0");
 }
 
+// [pcsamp:kernel.prologue]
 __device__ __forceinline__ void load_dec_image(float* __restrict__ W, const float* __restrict__ img) {
     for (int i = threadIdx.x * 4; i < DEC_FLOATS; i += blockDim.x * 4)
         *reinterpret_cast<f32x4*>(W + i) = *reinterpret_cast<const f32x4*>(img + i);
@@ -1006,6 +1028,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #endif
     constexpr bool CARRY = S == 1 && IFD_CARRY_KNNPT != 0;
     KnnPt ka_c = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false}, kb_c = ka_c;
+// [pcsamp:step.head]
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
         const bool want_loss = last && loss_out != nullptr;
@@ -1038,6 +1061,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         // bench launch at priority 2, 921 at equal priority, 973 with two tiles first - f32 MFMA and VALU share the issue
         // cycles, a lone tile wave runs at about half the paired rate, and the phases side by side only lengthen both.)
         // ---- decoder tiles, pulled from an LDS counter until the step's tiles run out -----------------------------------
+// [pcsamp:step.tile_loop]
         auto run_tiles = [&]() __attribute__((always_inline)) {
 #pragma unroll 1
             for (;;) {
@@ -1063,6 +1087,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #endif
             }
         };
+// [pcsamp:step.knn_call]
 #ifndef IFD_SPLIT_KNN_PRIO
 #define IFD_SPLIT_KNN_PRIO 2          // 0: tiles first (kNN at the end of the step); 1 / 2 / 3: kNN first at that wave priority
 #endif
@@ -1105,6 +1130,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
         if (S == 1 || IFD_SPLIT_KNN_PRIO != 0) { PROF_T0(); run_tiles(); }
         PROF_ACC(pc_tiles);
+// [pcsamp:step.adam]
         // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------
         AdamState ast;
         KnnPt ka, kb;
@@ -1150,6 +1176,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         TRACE_STAMP(29, "s_waitcnt lgkmcnt(0)");              // PIX written
         if (owner) store_adam(MV, tid_s, ast);
         adam_displacement(K, pa, pb, member * OW + wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
+// [pcsamp:step.end_barrier]
         if (CARRY) { ka_c = ka; kb_c = kb; }
         if (S == 1) {
             if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }   // both consumed before the mid-step barrier
@@ -1188,6 +1215,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         PROF_ACC(pc_adam);
     }
 
+// [pcsamp:kernel.epilogue]
     if (counters != nullptr) {
         if (tid < CN_COUNT) {
             constexpr int SLOT[CN_COUNT] = {0, 1, 2, 4, 5, 6, 7};     // rebuilds, exact scans, extra passes, ring evaluations,
@@ -1243,6 +1271,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// [pcsamp:other_kernels]
 // stand-alone entry kernels (same device functions; used by ifd_decode / ifd_repulsion and tests)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(OPT_THREADS, 2) void decode_kernel(const float* __restrict__ dec_img,
