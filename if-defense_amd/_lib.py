@@ -13,7 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IFD_LIB") or os.path.join(HERE, "csrc", "libifd.so")
 
 IFD_OK = 0
-ABI_VERSION = 1
+IFD_ERR_TIMEOUT = -5
+IFD_ERR_OVERFLOW = -6
+ABI_VERSION = 2
 
 
 class IfdConfig(C.Structure):
@@ -64,6 +66,7 @@ SIGNATURES = {
     "ifd_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ifd_get_counters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ifd_optimize_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ifd_normalize_unit_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     # ONet-Opt variant
     "ifd_onet_weight_count": (C.c_size_t, []),

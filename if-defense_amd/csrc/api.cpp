@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +21,8 @@
 
 // device-side size of the counter buffer: the IFD_N_COUNTERS public slots + the per-wave time stamps of -DIFD_TRACE builds
 constexpr int N_COUNTERS_DEV = IFD_N_COUNTERS + 8 * 32;
+static_assert(N_COUNTERS_DEV == ifd::DEV_COUNTERS, "the sticky status words sit right behind the counters (ifd_internal.h)");
+constexpr int N_COUNTERS_ALLOC = ifd::DEV_COUNTERS_TOTAL;      // + overflow / timeout status words (never cleared by an optimise call)
 
 using namespace ifd;
 
@@ -180,6 +183,17 @@ std::vector<float> build_dec_image(const float* w) {
 }
 
 bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > LARGE_MAXK; }
+
+// Bound of the cross-CU waits of split clouds (knn_device.h coop_wait) and the test hook that provokes it.  Environment, not
+// ifd_opt_params: neither is part of the path's interface.  IFD_COOP_TIMEOUT_MS (default 2000: a wait normally lasts
+// microseconds, a whole launch under a second); IFD_TEST_COOP_DROP=<member>: that member of every split cloud never arrives.
+void opt_env_hooks(OptArgs& a) {
+    double ms = 2000.0;
+    if (const char* t = std::getenv("IFD_COOP_TIMEOUT_MS")) { const double x = std::atof(t); if (x > 0.0) ms = x; }
+    a.coop_timeout_ticks = (unsigned int)std::min(4.0e9, ms * 1.0e5);          // 100 MHz wall clock (s_memrealtime)
+    a.test_drop_member = -1;
+    if (const char* d = std::getenv("IFD_TEST_COOP_DROP")) a.test_drop_member = std::atoi(d);
+}
 
 // Grow the context workspace.  Growing synchronises the device (hipFree), which only happens when a call
 // needs more scratch than any earlier call on this context.
@@ -350,8 +364,8 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         std::vector<float> img = build_dec_image(ctx->w.data());
         e = hipMemcpy(ctx->d_dec_img, img.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_DEV * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_w), n_weights * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w, ctx->w.data(), n_weights * sizeof(float), hipMemcpyHostToDevice);
     {
@@ -513,7 +527,9 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: not a ConvONet context (use ifd_onet_optimize)");
-    if (!planes || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
+    if (prm && prm->struct_size != (int32_t)sizeof(ifd_opt_params))
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: ifd_opt_params.struct_size does not match this library (caller built against another ifd.h?)");
+    if (!planes || !p || !prm || bad_bk(B, K))
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad argument (6 <= K <= 10000)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
@@ -525,6 +541,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;
+    opt_env_hooks(a);
     if (prm->split != 0 && prm->split != 1 && prm->split != 2 && prm->split != 4)
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: split must be 0 (automatic), 1, 2 or 4");
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (optimize.hip)
@@ -535,7 +552,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
     if (large) {
-        e = launch_large_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
+        e = launch_large_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
                                   static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
     }
@@ -547,15 +564,38 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n) {
     if (!ctx || !out_host || n < 1) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
-    unsigned long long tmp[N_COUNTERS_DEV] = {0};
+    unsigned long long tmp[N_COUNTERS_ALLOC] = {0};
     hipError_t e = hipMemcpy(tmp, ctx->d_counters, sizeof(tmp), hipMemcpyDeviceToHost);   // synchronises
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_get_counters", e);
     if (ctx->model == IFD_MODEL_ONET) {   // host-side tallies of the last ifd_onet_mesh_sample
         tmp[8] = ctx->mesh_points;
         tmp[9] = ctx->mesh_rounds;
     }
-    for (int i = 0; i < n; ++i) out_host[i] = i < N_COUNTERS_DEV ? tmp[i] : 0;   // slots >= IFD_N_COUNTERS: wave trace (diagnostic builds)
+    // slots >= IFD_N_COUNTERS: wave trace (diagnostic -DIFD_TRACE builds), the two status words (read-only here), tile trace
+    for (int i = 0; i < n; ++i) out_host[i] = i < N_COUNTERS_ALLOC ? tmp[i] : 0;
     return IFD_OK;
+}
+
+int ifd_optimize_status(ifd_ctx* ctx, void* stream) {
+    if (!ctx) return IFD_ERR_ARG;
+    IFD_ON_CTX_DEVICE(ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long st[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(st, ctx->d_counters + STATUS_OVERFLOW, sizeof(st), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize_status", e);
+    if (st[0] == 0 && st[1] == 0) return IFD_OK;
+    e = hipMemsetAsync(ctx->d_counters + STATUS_OVERFLOW, 0, sizeof(st), s);       // reported once
+    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize_status (reset)", e);
+    char msg[256];
+    if (st[1] != 0) {
+        std::snprintf(msg, sizeof(msg), "split clouds: %llu cross-CU wait(s) gave up (a member workgroup never arrived: CUs masked or "
+                      "held by another process?); the results of that launch are invalid - rerun with ifd_opt_params.split = 1", st[1]);
+        return fail(ctx, IFD_ERR_TIMEOUT, msg);
+    }
+    std::snprintf(msg, sizeof(msg), "repulsion gradient: the fixed-point sums of %llu point-step(s) reached half their range (|sum| >= 128; "
+                  "non-reference rep_radius / rep_h?); the results of that launch are invalid", st[0]);
+    return fail(ctx, IFD_ERR_OVERFLOW, msg);
 }
 
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream) {
@@ -634,8 +674,8 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     upload(&ctx->d_w, dev);
     upload(&ctx->d_onet_img, img);
     upload(&ctx->d_onet_small, small);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_DEV * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e == hipSuccess) e = configure_onet_kernels();
@@ -695,7 +735,9 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: not an ONet context");
-    if (!c || !p || !prm || prm->struct_size != (int32_t)sizeof(ifd_opt_params) || bad_bk(B, K))
+    if (prm && prm->struct_size != (int32_t)sizeof(ifd_opt_params))
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: ifd_opt_params.struct_size does not match this library (caller built against another ifd.h?)");
+    if (!c || !p || !prm || bad_bk(B, K))
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad argument (6 <= K <= 10000)");
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
@@ -705,6 +747,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     a.knn_scan_every_step = prm->knn_scan_every_step;
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
+    opt_env_hooks(a);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (onet.hip)
     hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : knn_list_bytes(B));
@@ -716,7 +759,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, s);
     if (e == hipSuccess && large)
         e = launch_onet_large_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
-                                       static_cast<const float*>(ctx->adam_tab), B, K, a, s);
+                                       ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K, a, s);
     else if (e == hipSuccess)
         e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
                                  static_cast<uint16_t*>(ctx->ws), ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K,

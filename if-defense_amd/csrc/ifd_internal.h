@@ -10,7 +10,19 @@ struct OptArgs {
     int steps, t0, loss_batch, normalize, knn_scan_every_step, planes_shared;
     float lr, rep_weight, threshold, rep_radius, rep_h, rep_eps;
     DecConst dc;
+    unsigned int coop_timeout_ticks;   // bound of a split cloud's cross-CU waits, in ticks of the 100 MHz wall clock (knn_device.h coop_wait)
+    int test_drop_member;              // test hook (env IFD_TEST_COOP_DROP): this member of every split cloud never arrives; -1 = off
 };
+
+// The context's device counter buffer (api.cpp d_counters, unsigned long long): IFD_N_COUNTERS public diagnostics of the last
+// optimise call, the wave trace of -DIFD_TRACE builds, then two STICKY status words that no optimise call clears
+// (ifd_optimize_status reads and resets them): points whose fixed-point repulsion sums came within a factor two of wrapping,
+// and cross-CU waits of split clouds that gave up.
+constexpr int DEV_COUNTERS = 16 + 8 * 32;
+constexpr int STATUS_OVERFLOW = DEV_COUNTERS;
+constexpr int STATUS_TIMEOUT = DEV_COUNTERS + 1;
+constexpr int TRACE2_BASE = DEV_COUNTERS + 2;        // -DIFD_TRACE2 builds: [8 waves][128] stamps inside one decoder tile per wave
+constexpr int DEV_COUNTERS_TOTAL = TRACE2_BASE + 8 * 128;
 
 // offsets (floats) of the point-net tensors inside the canonical weight vector (include/ifd.h order)
 struct EncPointOffsets {
@@ -61,15 +73,16 @@ hipError_t launch_normalize(float* p, int B, int K, hipStream_t s);
 // clouds of MAXK < K <= LARGE_MAXK optimised points: two launches per Adam step (optimize.hip, "large" section)
 size_t large_ws_bytes(int B, int K, bool own_moments);
 hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                                 const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B, int K,
-                                 const OptArgs& a, hipStream_t s);
+                                 const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
+                                 const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s);
 size_t large_f_bytes(int B, int K);           // global repulsion accumulators of clouds beyond LARGE_LDS_MAXK points (0 below)
 hipError_t large_f_prepare(void* ws, int B, int K, bool own_moments, void** f_ws, hipStream_t s);   // ... at the end of ws, zeroed
 hipError_t launch_large_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
                                   float h, float eps, void* f_ws, hipStream_t s);
 // one Adam step from the occupancy gradients G ([B][K] float4: d loss / d xyz, BCE term): exact 5-NN + repulsion + Adam
 hipError_t launch_large_step(float* p, float* m, float* v, const void* G, int B, int K, const float* adam_tab, int step,
-                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws, hipStream_t s);
+                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws,
+                             unsigned long long* counters, hipStream_t s);
 hipError_t launch_large_normalize(float* p, int B, int K, hipStream_t s);
 
 // ---- ONet-Opt (onet.hip) --------------------------------------------------------------------------------
@@ -92,8 +105,8 @@ hipError_t launch_onet_decode(const float* img, const float* small, const float*
 // clouds of MAXK < K <= LARGE_MAXK points (ONet/opt_defense.py:27 has no limit): two launches per Adam step, ws as
 // large_ws_bytes
 hipError_t launch_onet_large_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
-                                      float* loss, const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B,
-                                      int K, const OptArgs& a, hipStream_t s);
+                                      float* loss, const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
+                                      const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s);
 hipError_t launch_onet_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
                                 float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists,
                                 unsigned long long* counters, const float* adam_tab, int B, int K, const OptArgs& a,

@@ -572,6 +572,17 @@ __device__ __forceinline__ void unpack_xy(long long s, int& x, int& y) {
     x = (int)((s - (long long)y) >> 32);
 }
 
+// Headroom check of the sums a point received this step (Adam phase, large_take_f): a sum at or beyond 2^30 (= 128.0; the
+// bound derived above is 91) is within a factor two of wrapping into the neighbouring component / the sign bit, and a
+// single saturated term (fix32 saturates at +-256: |coef * e| that large needs non-reference radius / h parameters) lands
+// there too.  The launch's sticky overflow word counts such points; ifd_optimize_status() turns it into IFD_ERR_OVERFLOW.
+__device__ __forceinline__ void rep_overflow_check(const int (&fi)[3], unsigned long long* status) {
+    auto mag = [](int v) { return v < 0 ? 0u - (unsigned int)v : (unsigned int)v; };          // (|INT_MIN| = 2^31)
+    const unsigned int big = max(max(mag(fi[0]), mag(fi[1])), mag(fi[2]));
+    if (__builtin_expect(big >= (1u << 30), 0) && status != nullptr)
+        __hip_atomic_fetch_add(status + STATUS_OVERFLOW, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Split clouds (optimize.hip, "cooperative mode"): S = 2 or 4 workgroups - on as many CUs - share one cloud.  Member m owns
 // the points {vt, vt + 512 : vt in [m * 512 / S, (m + 1) * 512 / S)}: their neighbour lists, their repulsion terms, their
@@ -589,18 +600,24 @@ __device__ __forceinline__ void unpack_xy(long long s, int& x, int& y) {
 // [pcsamp:coop]
 constexpr int MAX_COOP_WAVES = 16;    // owner waves of a split cloud: S members x (8 at S = 2, 4 at S = 4) = MAX_WAVES
 struct CoopWs {
-    f32x4 X[MAXK];                    // positions after the last Adam step (written by the owners)
+    // Positions, maxima and flags are double-buffered by step parity: a member that has passed bar_step(t) may run the whole
+    // of step t + 1 - and publish its results - while a slower member is still copying the step-t values; the buffer of parity
+    // p is only written again in step t + 2, i.e. behind bar_step(t + 1), at which the slower member arrives after its copy.
+    // (With the repulsion term on, the bar_knn rendezvous in the middle of a step closed that window as well; without it
+    // nothing did.)
+    f32x4 X[2][MAXK];                 // positions after the last Adam step (written by the owners)
     long long Fxy[MAXK];              // neighbour terms received from other members, packed like RepAcc
     int Fz[MAXK];
     float L[MAXK][2];                 // last step only: BCE term, repulsion term of every point
-    float scal[MAX_COOP_WAVES][2];    // per owner wave of the cloud: displacement maximum, step-length maximum of the next step
-    int flag[4];                      // per member: whole-cloud list rebuild requested
+    float scal[2][MAX_COOP_WAVES][2]; // per owner wave of the cloud: displacement maximum, step-length maximum of the next step
+    int flag[2][4];                   // per member: whole-cloud list rebuild requested
     unsigned int bar_knn, bar_step;   // arrivals: members that have sent their neighbour terms; members that finished their step
     unsigned int pad[2];
 };
 struct CoopView {
     CoopWs* ws;
     int member;
+    int par;                          // parity of the exchange buffers this step publishes into ((step + 1) & 1)
 };
 template <int S>
 __device__ __forceinline__ bool coop_owns(int j, int member) {
@@ -608,13 +625,42 @@ __device__ __forceinline__ bool coop_owns(int j, int member) {
 }
 __device__ __forceinline__ float coop_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coop_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coop_publish() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// Every wave that stored to / did atomics on the exchange block calls this BEFORE the workgroup barrier or atomic that lets a
+// member arrive: on gfx9 one counter (vmcnt) covers loads, stores and atomics, and `s_waitcnt vmcnt(0)` returns when all of
+// them have been acknowledged by the L2 (sc1: written through).  The workgroup-scope release fence alone is NOT that: on
+// gfx950 it only waits for lgkmcnt (round-3 advisor finding, checked in the ISA: tests/test_abi_cpu.py greps the kernel).
+__device__ __forceinline__ void coop_publish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
 __device__ __forceinline__ void coop_arrive(unsigned int* ctr) {
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void coop_wait(unsigned int* ctr, unsigned int target) {      // (call it wave-uniformly)
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+// Wait until `ctr` reaches `target` (call it wave-uniformly).  The wait is BOUNDED: members of a split cloud are co-resident
+// by construction (one workgroup per CU, launch_optimize), but a CU mask, another process holding CUs with its own split
+// launch, or a member that died would otherwise leave the survivors spinning for ever (return a status,
+// never hang / exit).  After `limit` ticks of the 100 MHz wall clock (s_memrealtime) the waiter raises the launch's sticky
+// timeout word; every waiter that sees the word falls out at once, the kernel leaves its step loop at the next workgroup
+// barrier (results are garbage), and ifd_optimize_status() returns IFD_ERR_TIMEOUT.  Returns false if it gave up.
+__device__ __forceinline__ bool coop_wait(unsigned int* ctr, unsigned int target, unsigned long long* status, unsigned int limit) {
+    bool ok = true;
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned int it = 0;; ++it) {
+            if ((it & 31u) == 0u && status != nullptr) {
+                if (__hip_atomic_load(status + STATUS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { ok = false; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) {
+                    __hip_atomic_fetch_add(status + STATUS_TIMEOUT, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
 }
 // one neighbour (or centre) term into the accumulators of point j.  Split clouds accumulate the terms of points another
 // member owns in their OWN LDS entries for those points first (unused otherwise) and send every entry once per step
@@ -652,7 +698,7 @@ __device__ __forceinline__ void coop_flush_remote(const RepAcc F, const CoopView
 template <int S = 1>
 __device__ __forceinline__ void rep_point2(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
                                            const Top5& ta, const Top5& tb, const RepConst rc, float& loss_a,
-                                           float& loss_b, const CoopView cv = CoopView{nullptr, 0}) {
+                                           float& loss_b, const CoopView cv = CoopView{nullptr, 0, 0}) {
     const bool va = pa < K, vb = pb < K;
     const f32x4 xa = X[min(pa, K - 1)], xb = X[min(pb, K - 1)];
     const int ia[5] = {ta.i0, ta.i1, ta.i2, ta.i3, ta.i4}, ib[5] = {tb.i0, tb.i1, tb.i2, tb.i3, tb.i4};
@@ -804,7 +850,7 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
                                           int wave, int lane, int step, bool last, bool scan_every_step,
                                           const uint16_t* La, const uint16_t* Lb, uint16_t* cloud_lists, KnnPt& ka,
                                           KnnPt& kb, const KnnShared& sh, const RepConst rc, float& rep_loss_a,
-                                          float& rep_loss_b, KnnCounters& cn, const CoopView cv = CoopView{nullptr, 0}) {
+                                          float& rep_loss_b, KnnCounters& cn, const CoopView cv = CoopView{nullptr, 0, 0}) {
     float* const dmaxbuf = sh.dmaxbuf;
     float* const movebuf = sh.movebuf;
     volatile int* const rebuild_flag = sh.rebuild_flag;
@@ -987,7 +1033,7 @@ template <int S = 1>
 __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* __restrict__ G, const RepAcc F,
                                            int K, int pa, int pb, float step_size, float bc2, float rep_scale,
                                            AdamState& st, float (&xnew)[2][3], float& mv2_out,
-                                           const CoopView cv = CoopView{nullptr, 0}) {
+                                           unsigned long long* status = nullptr, const CoopView cv = CoopView{nullptr, 0, 0}) {
     float (&mm)[6] = st.mm;
     float (&vv)[6] = st.vv;
     // ---- Adam (torch/optim/adam.py _single_tensor_adam: lerp form, eps added after the bias-
@@ -1014,6 +1060,7 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             unpack_xy(fxy, fi[0], fi[1]);
             F.xy[pt] = 0;
             F.z[pt] = 0;
+            rep_overflow_check(fi, status);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 // (every multiply-add spelled as an fma, see rep_point2: the one- and the two-point instantiations of this
@@ -1036,7 +1083,7 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
             mv2 = fmaxf(mv2, msq);
             X[pt] = f32x4{xs[0], xs[1], xs[2], 1.f};     // .w = 1: fc_p's bias input on the matrix pipe (optimize.hip)
             if (S > 1) {
-                float* xg = reinterpret_cast<float*>(cv.ws->X + pt);
+                float* xg = reinterpret_cast<float*>(cv.ws->X[cv.par] + pt);
                 coop_st(xg, xs[0]); coop_st(xg + 1, xs[1]); coop_st(xg + 2, xs[2]);
             }
         }
@@ -1051,7 +1098,7 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
 // round trip of the wave that reached the barrier last hides under that work instead of stalling it.
 __device__ __forceinline__ void adam_displacement(int K, int pa, int pb, int wave, int lane, int step,
                                                   const float (&xnew)[2][3], float mv2, const KnnPt& ka, const KnnPt& kb,
-                                                  const KnnShared& sh) {
+                                                  const KnnShared& sh, bool owner_wave = true) {
     float dmax2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1065,7 +1112,7 @@ __device__ __forceinline__ void adam_displacement(int K, int pa, int pb, int wav
     }
     dmax2 = wave_max(dmax2);
     mv2 = wave_max(mv2);
-    if (lane == 0) {
+    if (lane == 0 && owner_wave) {      // (split clouds: the waves without owner threads have no slot - theirs would be a peer's)
         sh.dmaxbuf[((step + 1) & 1) * MAX_WAVES + wave] = dmax2 * 1.00001f + 1e-7f;
         sh.movebuf[((step + 1) & 1) * MAX_WAVES + wave] = sqrtf(mv2);
     }

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
             }
         }
         float xnew[2][3], mv2;
-        adam_phase(X, G, F, K, pa, pb, adam_tab[2 * step], adam_tab[2 * step + 1], rep_scale, ast, xnew, mv2);
+        adam_phase(X, G, F, K, pa, pb, adam_tab[2 * step], adam_tab[2 * step + 1], rep_scale, ast, xnew, mv2, counters);
         adam_displacement(K, pa, pb, wave, lane, step, xnew, mv2, ka, kb, ksh);
         if (tid == 0) rebuild_flag[step & 1] = 0;
         __syncthreads();
@@ -628,8 +628,8 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_large_occupancy_kernel(
 }
 
 hipError_t launch_onet_large_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
-                                      float* loss, const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B,
-                                      int K, const OptArgs& a, hipStream_t s) {
+                                      float* loss, const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
+                                      const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {
     f32x4* G = static_cast<f32x4*>(ws);
     void* f_ws = nullptr;                  // global repulsion accumulators beyond LARGE_LDS_MAXK points (end of ws)
     {
@@ -648,7 +648,7 @@ hipError_t launch_onet_large_optimize(const float* img, const float* small, cons
         hipLaunchKernelGGL(onet_large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, p, K,
                            loss_batch_per_cloud, a.loss_batch, a.threshold, G);
         hipError_t e = launch_large_step(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a,
-                                         step == a.steps - 1 ? loss : nullptr, f_ws, s);
+                                         step == a.steps - 1 ? loss : nullptr, f_ws, counters, s);
         if (e != hipSuccess) return e;
     }
     return a.normalize ? launch_large_normalize(p, B, K, s) : hipGetLastError();

@@ -549,12 +549,23 @@ __device__ __forceinline__ void sub_geometry(SubGeo& g, const f32x4 pp, float ks
 // [pcsamp:tile.setup]
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
+// -DIFD_TRACE -DIFD_TRACE2=<n>: time stamps INSIDE the n-th decoder tile a wave runs in the traced step (scripts/tile_trace.py):
+// one stamp per software-pipeline region of the MLP and per section around it, 128 slots per wave behind the status words
+// of the counter buffer.  A stamp is an s_memtime + s_waitcnt lgkmcnt(0) + one store by lane 0 - it drains the wave's LDS
+// prefetches at the region boundary, so a traced tile runs a few per cent slower than an untraced one.
+#ifdef IFD_TRACE2
+#define T2(slot) do { if (tr != nullptr) { const unsigned long long t2_ = __builtin_readcyclecounter(); if (lane == 0) tr[slot] = t2_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define T2(slot)
+#endif
+
 template <int MODE>
 __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amdgpu_buffer_rsrc_t planes,
                                               const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, int lane,
                                               const DecConst dc, float thr, float inv_lb, bool want_loss,
-                                              float (&bce)[2], float (&dx)[2][3]) {
+                                              float (&bce)[2], float (&dx)[2][3], [[maybe_unused]] unsigned long long* tr = nullptr) {
     constexpr int TV = 1;
+    T2(0);                                       // tile entered
     const int n = lane & 15, q = lane >> 4;
     LaneOff lo = {n * W_STRIDE + wperm(4 * q), 4 * q * W_STRIDE + wperm(n), 4 * q};
     asm volatile("" : "+v"(lo.fwd), "+v"(lo.bwd), "+v"(lo.q4));
@@ -652,12 +663,18 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         load_taps(1, tap1, false);
         load_taps(2, tap2, false);               // all three planes in flight (192 registers; nothing else is live yet)
         __builtin_amdgcn_sched_barrier(0);
+        T2(1);                                   // 48 tap loads issued
+#ifdef IFD_TRACE2
+        if (tr != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        T2(2);                                   // taps here
+#endif
         sample_fwd(0, tap0);
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(1, tap1);
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(2, tap2);
         __builtin_amdgcn_sched_barrier(0);
+        T2(3);                                   // forward sampling done
     }
 
 // [pcsamp:tile.fc_p]
@@ -682,6 +699,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     }
     WFrag A = load_wfrag<false>(Wd, lo);         // weights of the first layer (after the gather: its registers are free now)
     __builtin_amdgcn_sched_barrier(0);
+    T2(4);                                       // fc_p issued, first weights requested
 
 // [pcsamp:tile.fwd_mlp]
     // ---- forward MLP, software pipelined ---------------------------------------------------------------------
@@ -697,6 +715,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         Acc2 a0 = net[0], a1 = net[1];
         mfma16(A, c[0], a0);                                                  // R1
         region_end<0, 0>();
+        T2(5 + 6 * i + 0);
         const WFrag A0 = load_wfrag<false>(Wl + W_LAYER, lo);                 // R2: prefetch fc_0
         const Acc2 B0 = bias(3 * i + 1);
         mfma16(A, c[1], a1);
@@ -704,12 +723,14 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         const f32x8 ra0 = relu8(af0);
         mask_a[0][i] = mask_alive_packed(af0, ra0, c31);
         region_end<TV, 1>();
+        T2(5 + 6 * i + 1);
         Acc2 h0 = B0;                                                          // R3
         mfma16(A0, ra0, h0);
         const f32x8 af1 = flat(a1);
         const f32x8 ra1 = relu8(af1);
         mask_a[1][i] = mask_alive_packed(af1, ra1, c31);
         region_end<TV, 0>();
+        T2(5 + 6 * i + 2);
         const WFrag A1 = load_wfrag<false>(Wl + 2 * W_LAYER, lo);             // R4: prefetch fc_1
         const Acc2 B1 = bias(3 * i + 2);
         Acc2 h1 = B0;
@@ -718,12 +739,14 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         const f32x8 rh0 = relu8(hf0);
         mask_h[0][i] = mask_alive_packed(hf0, rh0, c31);
         region_end<TV, 1>();
+        T2(5 + 6 * i + 3);
         Acc2 o0 = acc_add(B1, a0);                                             // R5
         mfma16(A1, rh0, o0);
         const f32x8 hf1 = flat(h1);
         const f32x8 rh1 = relu8(hf1);
         mask_h[1][i] = mask_alive_packed(hf1, rh1, c31);
         region_end<TV, 0>();
+        T2(5 + 6 * i + 4);
         if (i + 1 < NBLK) {                                                    // R6: prefetch next fc_c / first fc_1^T
             A = load_wfrag<false>(Wl + 3 * W_LAYER, lo);
         } else {
@@ -741,6 +764,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         net[0] = o0;
         net[1] = o1;
         region_end<0, 1>();
+        T2(5 + 6 * i + 5);
     }
 // [pcsamp:tile.logit]
     f32x8 dn[2];
@@ -779,6 +803,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    T2(35);                                      // logits, loss derivative, seed of the backward pass
 
 // [pcsamp:tile.bwd_mlp]
     // ---- backward, software pipelined (A holds fc_1[4]^T) ----------------------------------------------------------
@@ -789,15 +814,18 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         Acc2 z0 = acc_zero();                                                  // R1: fc_1^T dn (sub-tile 0)
         mfma16(A, dn[0], z0);
         region_end<0, 0>();
+        T2(36 + 6 * (NBLK - 1 - i) + 0);
         const WFrag A0 = load_wfrag<true>(Wl + W_LAYER, lo);                  // R2: prefetch fc_0^T
         Acc2 z1 = acc_zero();
         mfma16(A, dn[1], z1);
         const f32x8 dh0 = masked(z0, mask_h[0][i]);
         region_end<1, 1>();
+        T2(36 + 6 * (NBLK - 1 - i) + 1);
         Acc2 y0 = acc_zero();                                                  // R3: fc_0^T dh (sub-tile 0)
         mfma16(A0, dh0, y0);
         const f32x8 dh1 = masked(z1, mask_h[1][i]);
         region_end<1, 0>();
+        T2(36 + 6 * (NBLK - 1 - i) + 2);
         const WFrag Ac = load_wfrag<true>(Wl, lo);                            // R4: prefetch fc_c^T
         Acc2 y1 = acc_zero();
         mfma16(A0, dh1, y1);
@@ -806,15 +834,18 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             add8_pk(dn[0], t);                                                 // delta a_i
         }
         region_end<1, 1>();
+        T2(36 + 6 * (NBLK - 1 - i) + 3);
         mfma16(Ac, dn[0], dcc[0]);                                             // R5: dc += fc_c^T da (sub-tile 0)
         {
             const f32x8 t = masked(y1, mask_a[1][i]);
             add8_pk(dn[1], t);
         }
         region_end<1, 0>();
+        T2(36 + 6 * (NBLK - 1 - i) + 4);
         if (i > 0) A = load_wfrag<true>(Wl - W_LAYER, lo);                    // R6: prefetch fc_1[i-1]^T
         mfma16(Ac, dn[1], dcc[1]);
         region_end<0, 1>();
+        T2(36 + 6 * (NBLK - 1 - i) + 5);
     }
     asm volatile("s_setprio 0");
 // [pcsamp:tile.fc_p_bwd]
@@ -870,9 +901,15 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         // two planes in flight (three spill here, and starting the re-gather under the last MLP block does too:
         // both measured slower)
         f32x4 btap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
+        T2(66);                                  // fc_p backward done
         load_taps(0, btap0, true);
         load_taps(1, tap1, true);
         __builtin_amdgcn_sched_barrier(0);
+        T2(67);                                  // re-gather of two planes issued
+#ifdef IFD_TRACE2
+        if (tr != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        T2(68);                                  // ... here
+#endif
         sample_bwd(0, btap0);
         __builtin_amdgcn_sched_barrier(0);
         load_taps(2, tap2, true);
@@ -881,6 +918,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         __builtin_amdgcn_sched_barrier(0);
         sample_bwd(2, tap2);
         __builtin_amdgcn_sched_barrier(0);
+        T2(69);                                  // backward sampling done
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -888,6 +926,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         for (int a = 0; a < 3; ++a) {
             dx[t][a] = add_lane_xor32(add_lane_xor16(g[t][a]));
         }
+    T2(70);                                      // tile left
     asm volatile("s_setprio 0");
 }
 
@@ -928,6 +967,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     constexpr int PTS = MAXK / S;                     // points of this member
     constexpr int OT = S == 1 ? OPT_THREADS : (PTS < OPT_THREADS ? PTS : OPT_THREADS);      // owner threads
     constexpr int OW = OT / 64;                       // ... and owner waves
+    static_assert(S * OW <= MAX_WAVES && S * OW <= MAX_COOP_WAVES, "one maxima slot per owner wave of the cloud");
     K = K < MAXK ? K : MAXK;                          // (the launcher guarantees it; spelled out so that pb < K folds to false)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* W = smem;                                                 // decoder parameter image
@@ -944,7 +984,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const int cloud = S == 1 ? (int)blockIdx.x : (int)(((blockIdx.x >> 3) / S) * 8 + (blockIdx.x & 7));
     const int member = S == 1 ? 0 : (int)((blockIdx.x >> 3) % S);
     if (S > 1 && cloud >= n_clouds) return;
-    const CoopView cv = {S > 1 ? coop + cloud : nullptr, member};
+    CoopWs* const cws = S > 1 ? coop + cloud : nullptr;
+    const CoopView cv = {cws, member, 0};
+    unsigned long long* const status = counters;      // sticky status words at STATUS_OVERFLOW / STATUS_TIMEOUT (ifd_internal.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pl = planes + (size_t)cloud * (A.planes_shared ? 0 : CLOUD_PLANE_FLOATS);
     float* pc = p + (size_t)cloud * K * 3;
@@ -1006,11 +1048,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);   // [2] by step parity
     int* tile_ctr = reinterpret_cast<int*>(scratch + 30);            // next decoder tile of this step
     int* knn_done = reinterpret_cast<int*>(scratch + 31);            // split clouds: owner waves of this member past their kNN phase
+    int* coop_abort = reinterpret_cast<int*>(scratch + 27);          // split clouds: a cross-CU wait of this member gave up (coop_wait)
     unsigned int* lcnt = reinterpret_cast<unsigned int*>(scratch + 96);           // [CN_COUNT] event counters
     const KnnShared ksh = {dmaxbuf, movebuf, rebuild_flag};
 
     if (tid < 2) rebuild_flag[tid] = 0;
-    if (tid == 0) { *tile_ctr = 0; *knn_done = 0; }
+    if (tid == 0) { *tile_ctr = 0; *knn_done = 0; *coop_abort = 0; }
     if (tid < CN_COUNT) lcnt[tid] = 0u;
     if (tid < 2 * MAX_WAVES) {
         dmaxbuf[tid] = 0.f;
@@ -1040,6 +1083,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         const int lane = tid_s & 63, wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
         const bool owner = tid_s < OT;
         const int pa = owner ? point_a(tid_s) : MAXK, pb = (S == 1 && owner) ? tid_s + OPT_THREADS : MAXK;
+        const CoopView cv = {cws, member, (step + 1) & 1};              // this step publishes into the buffers of parity (step + 1) & 1
+        const bool arrives = S == 1 || member != A.test_drop_member;    // (test hook: a member that never arrives, coop_wait's bound)
 #if defined(IFD_PROF)
         KnnCounters cn{lcnt, lane, lprof + wave * PC_COUNT};
 #elif defined(IFD_TRACE)
@@ -1075,8 +1120,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
                 float bce[2], dx[2][3];
                 const float* Xf = reinterpret_cast<const float*>(X) + (lane >> 4);      // component q of the point: fc_p's B operand
+#ifdef IFD_TRACE2
+                unsigned long long* tr2 = (cn.pc != nullptr && trace_tile == IFD_TRACE2) ? counters + TRACE2_BASE + wave * 128 : nullptr;
+                if (tr2 != nullptr && lane == 0) tr2[71] = (unsigned long long)tile;
+                decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
+                                        A.threshold, inv_lb, want_loss, bce, dx, tr2);
+#else
                 decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
                                         A.threshold, inv_lb, want_loss, bce, dx);
+#endif
                 if (lane < 16) {
                     if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
                     if (ib < K) G[tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
@@ -1123,7 +1175,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                 if (__builtin_amdgcn_readfirstlane(done) == OW - 1) {
                     coop_flush_remote<S>(F, cv, K, lane);
                     coop_publish();
-                    if (lane == 0) { *knn_done = 0; coop_arrive(&cv.ws->bar_knn); }
+                    if (lane == 0) { *knn_done = 0; if (arrives) coop_arrive(&cv.ws->bar_knn); }
                 }
                 if (IFD_SPLIT_KNN_PRIO != 0) asm volatile("s_setprio 0");
             }
@@ -1141,7 +1193,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         const f32x4 rl = park[z3 + PARK_KNN + 3];
         const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
         // split clouds: every owner wave of the cloud has sent its neighbour terms (the wait rode under the decoder tiles)
-        if (S > 1 && use_rep && wave == 0) coop_wait(&cv.ws->bar_knn, (unsigned int)(S * (step + 1)));
+        if (S > 1 && use_rep && wave == 0 &&
+            !coop_wait(&cv.ws->bar_knn, (unsigned int)(S * (step + 1)), status, A.coop_timeout_ticks) && lane == 0)
+            *coop_abort = 1;
         __syncthreads();
         PROF_ACC(pc_wait);
         if (S > 1 && want_loss) {   // the last step's per-point loss terms, reduced over the whole cloud after the loop
@@ -1166,7 +1220,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             }
         }
         float xnew[2][3], mv2;
-        adam_phase<S>(X, G, F, K, pa, pb, step_size, bc2, rep_scale, ast, xnew, mv2, cv);
+        adam_phase<S>(X, G, F, K, pa, pb, step_size, bc2, rep_scale, ast, xnew, mv2, status, cv);
         TRACE_STAMP(28, "s_waitcnt lgkmcnt(0)");              // Adam update done, X written
 #pragma unroll
         for (int q = 0; q < 2; ++q) {        // sampling coordinates of the moved points, for the next step's decoder tiles
@@ -1175,7 +1229,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         }
         TRACE_STAMP(29, "s_waitcnt lgkmcnt(0)");              // PIX written
         if (owner) store_adam(MV, tid_s, ast);
-        adam_displacement(K, pa, pb, member * OW + wave, lane, step, xnew, mv2, ka, kb, ksh);     // needs the parked state: last
+        adam_displacement(K, pa, pb, member * OW + wave, lane, step, xnew, mv2, ka, kb, ksh, wave < OW);     // needs the parked state: last
 // [pcsamp:step.end_barrier]
         if (CARRY) { ka_c = ka; kb_c = kb; }
         if (S == 1) {
@@ -1185,29 +1239,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             // ---- the step's exchange between the members of a split cloud ------------------------------------------------
             const int np = (step + 1) & 1;
             if (wave < OW && lane == 0) {      // this owner wave's certificate maxima of the next step (adam_displacement)
-                coop_st(&cv.ws->scal[member * OW + wave][0], dmaxbuf[np * MAX_WAVES + member * OW + wave]);
-                coop_st(&cv.ws->scal[member * OW + wave][1], movebuf[np * MAX_WAVES + member * OW + wave]);
+                coop_st(&cv.ws->scal[np][member * OW + wave][0], dmaxbuf[np * MAX_WAVES + member * OW + wave]);
+                coop_st(&cv.ws->scal[np][member * OW + wave][1], movebuf[np * MAX_WAVES + member * OW + wave]);
             }
-            if (tid == 0) __hip_atomic_store(&cv.ws->flag[member], (int)rebuild_flag[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(&cv.ws->flag[np][member], (int)rebuild_flag[np], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             coop_publish();                    // positions (adam_phase), maxima, flag: complete before this member arrives
             __syncthreads();
             if (wave == 0) {
-                if (lane == 0) coop_arrive(&cv.ws->bar_step);
-                coop_wait(&cv.ws->bar_step, (unsigned int)(S * (step + 1)));
+                if (lane == 0 && arrives) coop_arrive(&cv.ws->bar_step);
+                if (!coop_wait(&cv.ws->bar_step, (unsigned int)(S * (step + 1)), status, A.coop_timeout_ticks) && lane == 0)
+                    *coop_abort = 1;
             }
             if (tid == 0) { rebuild_flag[step & 1] = 0; *tile_ctr = 0; }
             __syncthreads();
+            if (*coop_abort != 0) break;       // a member never came (block-uniform): leave with what there is, the status word is set
             for (int i = tid_s; i < K; i += NW * 64)       // the other members' points
                 if (!coop_owns<S>(i, member)) {
-                    const float* xg = reinterpret_cast<const float*>(cv.ws->X + i);
+                    const float* xg = reinterpret_cast<const float*>(cv.ws->X[np] + i);
                     X[i] = f32x4{coop_ld(xg), coop_ld(xg + 1), coop_ld(xg + 2), 1.f};
                 }
             if (tid_s < S * OW && tid_s / OW != member) {     // ... and their owner waves' maxima (slot = owner wave of the cloud)
-                dmaxbuf[np * MAX_WAVES + tid_s] = coop_ld(&cv.ws->scal[tid_s][0]);
-                movebuf[np * MAX_WAVES + tid_s] = coop_ld(&cv.ws->scal[tid_s][1]);
+                dmaxbuf[np * MAX_WAVES + tid_s] = coop_ld(&cv.ws->scal[np][tid_s][0]);
+                movebuf[np * MAX_WAVES + tid_s] = coop_ld(&cv.ws->scal[np][tid_s][1]);
             }
             if (tid_s >= 64 && tid_s < 64 + S && tid_s - 64 != member) {     // the other members' expiring certificates
-                const int nbad = __hip_atomic_load(&cv.ws->flag[tid_s - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int nbad = __hip_atomic_load(&cv.ws->flag[np][tid_s - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (nbad != 0) atomicAdd(const_cast<int*>(rebuild_flag) + np, nbad);
             }
             __syncthreads();
@@ -1434,7 +1490,7 @@ static size_t large_lds_bytes(int K) { return K <= LARGE_LDS_MAXK ? LARGE_LDS : 
 size_t large_f_bytes(int B, int K) { return K <= LARGE_LDS_MAXK ? 0 : (size_t)B * K * 12; }
 // what a point received (GF: read past the L1 - the sums were made by atomics in the L2 - and cleared for the next step)
 template <bool GF>
-__device__ __forceinline__ void large_take_f(const RepAcc F, int pt, int (&fi)[3]) {
+__device__ __forceinline__ void large_take_f(const RepAcc F, int pt, int (&fi)[3], unsigned long long* status = nullptr) {
     if (GF) {
         const long long fxy = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(F.xy + pt), __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT);
@@ -1446,6 +1502,7 @@ __device__ __forceinline__ void large_take_f(const RepAcc F, int pt, int (&fi)[3
         unpack_xy(F.xy[pt], fi[0], fi[1]);
         fi[2] = F.z[pt];
     }
+    rep_overflow_check(fi, status);
 }
 
 // exact 5-NN + repulsion terms of the points of this thread, two at a time (the persistent kernel's rep_point2)
@@ -1475,7 +1532,8 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
                                                                     int K, const float* __restrict__ adam_tab, int step,
                                                                     const int32_t* __restrict__ loss_batch_per_cloud,
                                                                     int loss_batch, float rep_weight, RepConst rc,
-                                                                    float* __restrict__ loss_out, void* f_ws) {
+                                                                    float* __restrict__ loss_out, void* f_ws,
+                                                                    unsigned long long* status) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     const LargeLds l = large_lds<GF>(smem, K, (int)gridDim.x, cloud, f_ws);
@@ -1505,7 +1563,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
         const float gocc[3] = {go.x, go.y, go.z};
         float xs[3] = {x.x, x.y, x.z};
         int fi[3];
-        large_take_f<GF>(l.F, pt, fi);
+        large_take_f<GF>(l.F, pt, fi, status);
         const size_t o = ((size_t)cloud * K + pt) * 3;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {                         // the persistent kernel's adam_phase, term by term
@@ -1757,19 +1815,20 @@ hipError_t large_f_prepare(void* ws, int B, int K, bool own_moments, void** f_ws
     return hipMemsetAsync(*f_ws, 0, large_f_bytes(B, K), s);
 }
 static void large_step_launch(float* p, float* m, float* v, const f32x4* G, int B, int K, const float* adam_tab, int step,
-                              const int32_t* lbpc, const OptArgs& a, const RepConst& rc, float* loss, void* f_ws, hipStream_t s) {
+                              const int32_t* lbpc, const OptArgs& a, const RepConst& rc, float* loss, void* f_ws,
+                              unsigned long long* status, hipStream_t s) {
     if (K <= LARGE_LDS_MAXK)
         hipLaunchKernelGGL(large_step_kernel<false>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, m, v, G, K, adam_tab,
-                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws);
+                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws, status);
     else
         hipLaunchKernelGGL(large_step_kernel<true>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, m, v, G, K, adam_tab,
-                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws);
+                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws, status);
 }
 
 // ws: [B][K] f32x4 occupancy gradients, then (m == nullptr) the two moment arrays, zeroed here, then large_f_bytes
 hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                                 const int32_t* loss_batch_per_cloud, void* ws, const float* adam_tab, int B, int K,
-                                 const OptArgs& a, hipStream_t s) {
+                                 const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
+                                 const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {
     f32x4* G = static_cast<f32x4*>(ws);
     void* f_ws = nullptr;
     {
@@ -1789,7 +1848,7 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
         hipLaunchKernelGGL(large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
                            loss_batch_per_cloud, a.loss_batch, a.threshold, G, a.dc);
         large_step_launch(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a, rc, (step == a.steps - 1) ? loss : nullptr,
-                          f_ws, s);
+                          f_ws, counters, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1801,9 +1860,10 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
 // of every point (f32x4: d loss / d xyz, BCE term), large_step_kernel does the exact 5-NN, the repulsion terms and Adam.
 // f_ws: large_f_prepare's pointer (nullptr up to LARGE_LDS_MAXK points)
 hipError_t launch_large_step(float* p, float* m, float* v, const void* G, int B, int K, const float* adam_tab, int step,
-                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws, hipStream_t s) {
+                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws,
+                             unsigned long long* counters, hipStream_t s) {
     const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
-    large_step_launch(p, m, v, static_cast<const f32x4*>(G), B, K, adam_tab, step, loss_batch_per_cloud, a, rc, loss, f_ws, s);
+    large_step_launch(p, m, v, static_cast<const f32x4*>(G), B, K, adam_tab, step, loss_batch_per_cloud, a, rc, loss, f_ws, counters, s);
     return hipGetLastError();
 }
 

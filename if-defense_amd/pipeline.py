@@ -78,6 +78,11 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
         for i, pc in enumerate(arrays):
             n = int(pc.shape[0])
             h = {"pc": pc, "x": None, "out": torch.empty(n, args.sample_npoint, 3, device=r.device, dtype=torch.float32)}
+            if on_gpu and torch.is_tensor(pc) and pc.is_cuda:
+                # a device tensor handed over lazily was produced on the main stream, by work queued before this moment:
+                # the side stream waits for exactly that (an event recorded now), not for the optimiser launches that follow
+                h["ev_in"] = torch.cuda.Event()
+                h["ev_in"].record(main)
             los = list(range(0, max(n, 1), int(args.chunk)))
             for lo in los:
                 yield i, h, lo, min(n, lo + int(args.chunk)), lo == los[-1]
@@ -86,6 +91,8 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
         """the array's points on the device - copied on the CURRENT stream (the side stream when passes overlap: a copy
         enqueued on the main stream would wait behind the optimiser launch it is supposed to run under)"""
         if h["x"] is None:
+            if side is not None and h.get("ev_in") is not None:
+                side.wait_event(h["ev_in"])
             h["x"] = torch.as_tensor(h["pc"])[..., :3].to(device=r.device, dtype=torch.float32).contiguous()
             h["pc"] = None
         return h["x"]
@@ -129,6 +136,11 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
                                                 lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing)
         ready = launch_prepare(nxt_u) if nxt_u is not None else None               # rides on the optimiser's tail
         if last:
+            if on_gpu and hasattr(r, "check_status") and os.environ.get("IFD_STATUS_CHECK", "1") != "0":
+                # device-side failures of this file's launches (a split cloud's wait that gave up, fixed-point sums near
+                # their range) raise here, once per file, where its result is handed on.  The synchronisation costs one launch
+                # latency: the next pass's pre-processing is already queued on the side stream.
+                r.check_status()
             yield h["out"]
         del h, cur_u
         cur_u, nxt_u = nxt_u, (next(it, None) if nxt_u is not None else None)

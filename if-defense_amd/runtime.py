@@ -199,13 +199,16 @@ class Restorer:
                         state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
                         return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
                         knn_scan_every_step: bool = False, printing: bool = False, split: int = 0,
-                        planes_shared: bool = False):
+                        planes_shared: bool = False, rep_radius: float = 0.07, rep_h: float = 0.03, check: bool = False):
         """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
         is given.  ``loss_batch`` is the reference batch size whose 1/B factor scales both losses
         (default: the number of clouds passed in); an int, or an int32 tensor [B] with one value per cloud.  ``state=(m, v, t0)`` resumes / teacher-forces.
         ``split``: CUs per cloud (ifd_opt_params.split: 0 automatic, 1 / 2 / 4 forced; same results).
+        ``rep_radius`` / ``rep_h``: RepulsionLoss(radius, h) (defense/repulsion_loss.py:9-10; the reference never changes them).
+        ``check``: synchronise and raise IfdError on a device-side failure (``check_status``); the drivers of pipeline.py
+        check once per file instead, where the result is consumed.
         Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
         is left to the caller.
         """
@@ -230,12 +233,14 @@ class Restorer:
                 raise IfdError("loss_batch tensor must have one entry per cloud")
             loss_batch = B
         prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
-                           float(lr), float(rep_weight), self.threshold, 0.07, 0.03, 1e-12,
+                           float(lr), float(rep_weight), self.threshold, float(rep_radius), float(rep_h), 1e-12,
                            int(bool(knn_scan_every_step)), int(split or _ENV_SPLIT), int(bool(planes_shared)))
         with torch.cuda.device(self.device):
             self._check(self._fn_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
                                               self._ptr(lb_arr), self._ptr(m), self._ptr(v), self._ptr(loss),
                                               self._stream()))
+        if check:
+            self.check_status()
         out = (p,)
         if return_state:
             out += ((m, v, t0 + n_steps),)
@@ -282,6 +287,13 @@ class Restorer:
             t += 1
         return p
 
+    def check_status(self):
+        """ifd_optimize_status: raise IfdError if an optimise launch since the last check failed on the device - a cross-CU
+        wait of a split cloud that gave up, fixed-point repulsion sums near their range (include/ifd.h).  Synchronises the
+        current stream."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.ifd_optimize_status(self.ctx, self._stream()))
+
     def counters(self) -> Dict[str, int]:
         """Diagnostic counters of the last optimize_points call (synchronises)."""
         buf = (C.c_uint64 * 16)()
@@ -297,6 +309,14 @@ class Restorer:
         buf = (C.c_uint64 * (16 + 8 * 32))()
         self._check(self.lib.ifd_get_counters(self.ctx, buf, 16 + 8 * 32))
         return [[int(buf[16 + w * 32 + i]) for i in range(32)] for w in range(8)]
+
+    def tile_trace(self):
+        """Time stamps (shader cycles) inside ONE decoder tile per wave of the traced step, [8 waves][128 slots] - only filled
+        by a -DIFD_TRACE -DIFD_TRACE2=<n> diagnostic build (scripts/tile_trace.py; slot map in optimize.hip decoder_tile3)."""
+        base = 16 + 8 * 32 + 2
+        buf = (C.c_uint64 * (base + 8 * 128))()
+        self._check(self.lib.ifd_get_counters(self.ctx, buf, base + 8 * 128))
+        return [[int(buf[base + w * 128 + i]) for i in range(128)] for w in range(8)]
 
     def normalize_batch_pc(self, points: torch.Tensor) -> torch.Tensor:
         """normalize_batch_pc (opt_defense.py:76-83); returns a new tensor."""

@@ -49,14 +49,17 @@
 extern "C" {
 #endif
 
-#define IFD_ABI_VERSION 1
+/* 2: ifd_opt_params grew (split, planes_shared - round 3), ifd_optimize_status and the two status codes below were added */
+#define IFD_ABI_VERSION 2
 
 enum {
     IFD_OK = 0,
     IFD_ERR_ARG = -1,        /* bad argument (NULL, size out of the supported range) */
     IFD_ERR_HIP = -2,        /* a HIP runtime call failed; see ifd_last_error() */
     IFD_ERR_UNSUPPORTED = -3,/* valid in the reference but not built here (e.g. 'grid' planes) */
-    IFD_ERR_NOMEM = -4
+    IFD_ERR_NOMEM = -4,
+    IFD_ERR_TIMEOUT = -5,    /* ifd_optimize_status: a cross-CU wait of a split cloud gave up (results of that launch invalid) */
+    IFD_ERR_OVERFLOW = -6    /* ifd_optimize_status: fixed-point repulsion sums reached half their range (results invalid) */
 };
 
 /* Resolved hyper-parameters (ConvONet/configs/convonet_3plane_mn40.yaml + default.yaml).
@@ -215,6 +218,20 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
  * diagnostic -DIFD_TRACE builds). */
 #define IFD_N_COUNTERS 16
 int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
+
+/* Device-side failures of the optimise calls issued on this context since the last call of this function (either model).
+ * The reference's own failure path in this loop is exit(-1) (ConvONet/defense/repulsion_loss.py:25-39, SOR.py:57-59); here
+ * nothing exits or hangs: the kernels raise sticky status words and this call reports them.  Synchronises `stream` (call it
+ * where the results are consumed), resets the words, returns
+ *   IFD_OK
+ *   IFD_ERR_TIMEOUT   a member workgroup of a split cloud (ifd_opt_params.split != 1) did not arrive within the bound of the
+ *                     cross-CU waits (2 s; environment IFD_COOP_TIMEOUT_MS) - CUs masked or held by another process's split
+ *                     launch.  Every waiter falls out, the launch ends early, its output is invalid.
+ *   IFD_ERR_OVERFLOW  the repulsion gradient of some point summed to |x| >= 128 in a step: the 32-bit fixed-point accumulators
+ *                     (2^-23 units, wrap at 256) are within a factor two of wrapping; with the reference's radius / h the sum
+ *                     is bounded by 91.  The output of that launch is invalid.
+ * ifd_last_error() carries the counts. */
+int ifd_optimize_status(ifd_ctx* ctx, void* stream);
 
 /* normalize_batch_pc (ConvONet/opt_defense.py:76-83) in place on p [B,K,3]. */
 int ifd_normalize_unit_sphere(ifd_ctx* ctx, float* p, int B, int K, void* stream);

@@ -51,7 +51,7 @@ def test_exports_are_c_abi():
 
 def test_abi_version_and_weight_count(lib):
     from ifdefense_amd import weights
-    assert lib.ifd_abi_version() == 1
+    assert lib.ifd_abi_version() == 2
     n = sum(int(np.prod(s)) for _, s in weights.canonical_keys())
     assert n == 16001 + 27232 + 1934976 == lib.ifd_weight_count()
 
@@ -175,3 +175,54 @@ def test_marching_cubes_single_cubes_against_live_reference_library():
             theirs = v[t.astype(int)] if len(t) else np.zeros((0, 3, 3))
             assert ours.shape == theirs.shape, (cfg, rep)
             np.testing.assert_allclose(ours, theirs, rtol=0, atol=1e-12, err_msg=str((cfg, rep)))
+
+
+def _gfx950_code_objects(path):
+    """The gfx950 code objects embedded in a host object / shared library (clang offload bundles in .hip_fatbin)."""
+    import struct
+    d = open(path, "rb").read()
+    out, i = [], 0
+    while True:
+        i = d.find(b"__CLANG_OFFLOAD_BUNDLE__", i)
+        if i < 0:
+            return out
+        n = struct.unpack_from("<Q", d, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", d, off)
+            off += 24
+            if b"gfx950" in d[off:off + tl]:
+                out.append(d[i + o:i + o + sz])
+            off += tl
+        i += 24
+
+
+def test_split_cloud_arrivals_are_preceded_by_a_vmcnt0_wait(lib, tmp_path):
+    """Round-3 advisor finding: a member of a split cloud must drain its stores / atomics to the exchange block
+    (`s_waitcnt vmcnt(0)`, knn_device.h coop_publish) before it bumps an arrival counter - the workgroup-scope release
+    fence alone emits no vmcnt wait on gfx950.  Checked in the shipped ISA: in optimize_kernel<8, 2> and <8, 4> the nearest
+    preceding memory-write-or-wait of every arrival atomic (a 32-bit global_atomic_add through an SGPR base) is the wait."""
+    import ifdefense_amd as I
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    found = {}
+    for k, co in enumerate(_gfx950_code_objects(I.LIB_PATH)):
+        f = tmp_path / ("co%d.elf" % k)
+        f.write_bytes(co)
+        txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True).stdout
+        if "optimize_kernelILi8ELi2E" not in txt:
+            continue
+        for sym in ("optimize_kernelILi8ELi2E", "optimize_kernelILi8ELi4E"):
+            body = txt[txt.index("<_ZN3ifd15" + sym):]
+            body = body[:body.index("s_endpgm")]
+            ins = [l.split("//")[0].strip() for l in body.splitlines()]
+            ins = [l for l in ins if l and not l.endswith(":")]
+            arrivals = [i for i, l in enumerate(ins) if re.match(r"global_atomic_add v\d+, v\d+, s\[", l)]
+            assert len(arrivals) >= 2, "expected the bar_knn and bar_step arrivals in " + sym
+            for a in arrivals:
+                prev = next(l for l in reversed(ins[:a])
+                            if l.startswith(("global_store", "global_atomic", "s_waitcnt vmcnt(0)")) or "vmcnt(0)" in l)
+                assert "vmcnt(0)" in prev and prev.startswith("s_waitcnt"), (sym, ins[max(0, a - 12):a + 1])
+            found[sym] = len(arrivals)
+    assert len(found) == 2, "optimize_kernel<8,2> / <8,4> not found in libifd.so"

@@ -330,6 +330,54 @@ def test_repulsion_accumulators_do_not_wrap_on_a_tight_cluster(restorer, golden,
     assert np.abs(g_rep - ref).max() < 2e-5 * np.abs(ref).max()
 
 
+def test_repulsion_overflow_is_reported_not_silent(restorer, golden, planes2):
+    """Runtime detection behind the headroom argument above (return a status; the reference's failure path
+    in this loop is exit(-1), defense/repulsion_loss.py:25-39).  With the reference's radius / h no launch raises the sticky
+    overflow word; with RepulsionLoss(radius=50) a single neighbour term is ~1e3 - it saturates the 32-bit fixed-point
+    conversion at +-256 - and ifd_optimize_status returns IFD_ERR_OVERFLOW once, for the persistent kernel, the split kernel
+    and the launch-per-step path of clouds beyond 1024 points."""
+    import ifdefense_amd as I
+    x = torch.from_numpy(golden["init_points"][:2])
+    restorer.check_status()                                                    # nothing pending from earlier tests
+    restorer.optimize_points(x, planes2, rep_weight=500.0, steps=5, check=True)
+    for kw in (dict(split=1), dict(split=2)):
+        with pytest.raises(I.IfdError, match="-6.*fixed-point"):
+            restorer.optimize_points(x, planes2, rep_weight=500.0, steps=2, rep_radius=50.0, check=True, **kw)
+        restorer.check_status()                                                # reported once, then clear
+    big = torch.cat([x, x + 0.003], dim=1)                                     # 2048 points: two launches per step
+    restorer.optimize_points(big, planes2, rep_weight=500.0, steps=2, check=True)
+    with pytest.raises(I.IfdError, match="-6"):
+        restorer.optimize_points(big, planes2, rep_weight=500.0, steps=2, rep_radius=50.0, check=True)
+    # an unchecked failure stays pending until somebody asks (the drivers of pipeline.py ask once per file)
+    restorer.optimize_points(x, planes2, rep_weight=500.0, steps=1, rep_radius=50.0)
+    restorer.optimize_points(x, planes2, rep_weight=500.0, steps=1)
+    with pytest.raises(I.IfdError, match="-6"):
+        restorer.check_status()
+
+
+def test_split_cloud_wait_is_bounded_and_reported(restorer, golden, planes2, monkeypatch):
+    """The members of a split cloud wait for each other across CUs (knn_device.h coop_wait).  The wait is bounded: with one
+    member's arrivals suppressed (test hook IFD_TEST_COOP_DROP) and the bound lowered to 20 ms, every other member gives up,
+    the launch ends within milliseconds instead of hanging the GPU, ifd_optimize_status returns IFD_ERR_TIMEOUT, and the
+    next launch on the context is clean and bit-identical to the unsplit kernel."""
+    import time
+    import ifdefense_amd as I
+    x = torch.from_numpy(golden["init_points"][:2]).cuda()
+    ref = restorer.optimize_points(x, planes2, rep_weight=500.0, steps=30, split=1, check=True)
+    monkeypatch.setenv("IFD_COOP_TIMEOUT_MS", "20")
+    for split, drop, rw in ((2, 1, 500.0), (4, 3, 500.0), (4, 0, 0.0)):
+        monkeypatch.setenv("IFD_TEST_COOP_DROP", str(drop))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with pytest.raises(I.IfdError, match="-5.*wait"):
+            restorer.optimize_points(x, planes2, rep_weight=rw, steps=300, split=split, check=True)
+        dt = time.perf_counter() - t0
+        print("split %d, member %d never arrives (rep_weight %g): launch ended after %.0f ms with IFD_ERR_TIMEOUT" % (split, drop, rw, dt * 1e3))
+        assert dt < 2.0, dt
+        monkeypatch.delenv("IFD_TEST_COOP_DROP")
+        assert torch.equal(restorer.optimize_points(x, planes2, rep_weight=500.0, steps=30, split=split, check=True), ref)
+
+
 def test_rep_weight_zero_and_small_k(restorer, golden, planes2, oracle_weights):
     from oracle import convonet_oracle as O
     init = torch.from_numpy(golden["init_points"][:2, :100]).clone()
