@@ -667,6 +667,192 @@ def test_defend_point_cloud_end_to_end_and_sharding(restorer, golden):
     assert np.array_equal(small, full)                                         # the memory knob does not change results
 
 
+# ------------------------------------------------------------------------------------------------
+# Attribution of out-of-tolerance points (round 4).  north_star's bound is 1e-3 per-point L2; on clustered / sparse inputs a
+# handful of points per 4096 end up beyond it after 10 free-running steps.  Instead of budgeting for them, every point whose
+# two trajectories separate (by more than 2e-5 in a coordinate - a fiftieth of the bound) must be EXPLAINED, by substitution
+# experiments on the two trajectories themselves.  The build's trajectory: one launch per step with the Adam state carried
+# (bit-equal to the one-launch run), gradient recovered from the first moment.  The oracle's: the reference's op sequence
+# with the gradient recorded before every Adam update.  At the step t where a point separates, the ORACLE's gradient is
+# evaluated twice more, at the BUILD's positions x_t: once as it is (G1) and once with the build's 5-NN sets substituted for
+# the expanded-form kNN of pn_utils.py:76-82 (G2).  With g_b / g_o the two sides' own gradients and `noise` = 1e-5 of the
+# step's largest gradient component (the hot kernel's gradient matches autograd to 5e-7 of it):
+#   B  neighbour choice          |g_b - G2| <= noise < |g_b - G1|: at identical positions the two implementations differ, and
+#                                they stop differing when the oracle is given the build's neighbour sets - the reference's
+#                                expanded-form f32 distance ranked two candidates the other way round (its noise is ~1e-7 for
+#                                coordinates of ~0.45; the kernel ranks exact differences).
+#   S  the oracle's sensitivity  |g_b - G1| <= noise < |G1 - g_o|: at identical positions the two implementations agree; the
+#                                ORACLE's own gradient moves by more than the noise between two sets of positions that agree to
+#                                2e-5 (a ReLU boundary of the decoder, a cell edge of grid_sample, a neighbour rank inside the
+#                                oracle): rounding-level differences of earlier steps amplified by the reference function itself.
+#   C  propagation               as S, but a neighbour of the point (its 5-NN on either side, or a point that counts it among
+#                                its 5-NN) separated at an earlier step: the repulsion term couples them.
+#   A  Adam at |g| ~ 0           all three gradients agree to noise and the diverging coordinate's gradient history is inside the
+#                                noise: torch.optim.Adam's update lr * m_hat / (sqrt(v_hat) + eps) is +-lr for any |g| >> eps in
+#                                the first steps (opt_defense.py:207, torch/optim/adam.py).
+#   R  a ReLU boundary inside   noise < |g_b - G1| = |g_b - G2|: the implementations differ at identical positions, whatever the
+#      the rounding              neighbour sets.  Demonstrated on the oracle alone: nudging the point by a few ulps makes the ORACLE's
+#                                own occupancy gradient jump by exactly that difference - a hidden unit of the decoder has a
+#                                pre-activation within f32 rounding of zero there, and the two summation orders land on
+#                                opposite sides (torch's threshold_backward, src/layers.py:39-47, has no 'almost').
+# A separating point with none of these FAILS the test.  The count of points beyond 1e-3 is additionally held against the
+# oracle's own sensitivity: the same oracle run from inputs moved by one ulp (five sign patterns).
+# ------------------------------------------------------------------------------------------------
+def _oracle_trace(MO, w, init, cond, steps, loss_batch):
+    """The oracle's optimize_points loop (opt_defense.py:205-228) with x_t and g_t kept: x [steps + 1, B, K, 3], g [steps, B, K, 3]."""
+    x = init.clone().float().requires_grad_(True)
+    opt = torch.optim.Adam([x], lr=1e-3)
+    xs, gs = [x.detach().clone()], []
+    for _ in range(steps):
+        total = MO.losses(w, x, cond, 500.0, 0.2, loss_batch)[0]
+        opt.zero_grad()
+        total.backward()
+        gs.append(x.grad.detach().clone())
+        opt.step()
+        xs.append(x.detach().clone())
+    return torch.stack(xs).numpy(), torch.stack(gs).numpy()
+
+
+def _oracle_grad(MO, w, x, cond, loss_batch, idx=None):
+    """The oracle's gradient of the step objective (opt_defense.py:212-225) at positions x [B,K,3]; idx [B,K,5]: neighbour sets
+    to use instead of the reference's expanded-form kNN."""
+    from oracle import convonet_oracle as O
+    import torch.nn.functional as F
+    p = torch.from_numpy(np.ascontiguousarray(x)).clone().requires_grad_(True)
+    logits = MO.decode_logits(w, p, cond)
+    bce = F.binary_cross_entropy_with_logits(logits, torch.full_like(logits, 0.2), reduction="none")
+    rep = O.repulsion_loss(p, None if idx is None else torch.from_numpy(idx).long())
+    (bce.sum() / float(loss_batch) + rep.sum() / float(loss_batch) * 500.0).backward()
+    return p.grad.numpy()
+
+
+def _oracle_kink_jumps(MO, w, x_point, cond_b, loss_batch, nudges=(0, 1, -1, 2, -2, 4, -4, 8, -8, 16, -16, 32, -32, 64, -64, 128, -128, 256, -256, 512, -512)):
+    """Occupancy-gradient jumps of the oracle at one point under nudges of 1 ... 512 ulps per coordinate (512 ulps of a
+    coordinate of 0.4 are 1.5e-5: below the separation threshold, and what a hidden unit's pre-activation - a sum of up to
+    256 terms of O(1) in another order - can differ by between two implementations): (gradient at the nudged position -
+    gradient at the position itself), [n, 3]."""
+    import itertools
+    import torch.nn.functional as F
+    offs = list(itertools.product(nudges, repeat=3))
+    bits = np.ascontiguousarray(x_point, dtype=np.float32).view(np.int32)
+    sgn = np.where(bits < 0, -1, 1).astype(np.int32)                       # (moving a negative float up = fewer magnitude bits)
+    pts = np.stack([(bits + sgn * np.array(o, dtype=np.int32)).view(np.float32) for o in offs])
+    p = torch.from_numpy(pts)[None].clone().requires_grad_(True)         # [1, n, 3]
+    logits = MO.decode_logits(w, p, cond_b)
+    (F.binary_cross_entropy_with_logits(logits, torch.full_like(logits, 0.2), reduction="none").sum() / float(loss_batch)).backward()
+    g = p.grad[0].numpy()
+    return g - g[offs.index((0, 0, 0))]
+
+
+def _hip_trace(r, init, cond, steps, loss_batch):
+    """The build's trajectory, one launch per Adam step with the state carried (x_t, and g_t recovered from the first moment:
+    m_t = 0.9 m_{t-1} + 0.1 g_t)."""
+    x, st = init, None
+    xs, gs = [init.cpu().numpy()], []
+    m_prev = np.zeros_like(xs[0])
+    for _ in range(steps):
+        x, st = r.optimize_points(x, cond, rep_weight=500.0, steps=1, loss_batch=loss_batch, normalize=False, state=st,
+                                  return_state=True)
+        m = st[0].cpu().numpy()
+        gs.append((m - 0.9 * m_prev) / 0.1)
+        m_prev = m
+        xs.append(x.cpu().numpy())
+    return np.stack(xs), np.stack(gs), x
+
+
+def _attribute_separations(r, MO, w, cond, loss_batch, hx, hg, ox, og, tag, onset_tol=2e-5, g_noise=1e-5):
+    """hx / ox [T + 1, B, K, 3], hg / og [T, B, K, 3]: the build's / the oracle's positions and gradients.  Classifies every
+    point whose trajectories separate (block comment above); fails on a point without an explanation."""
+    from oracle import convonet_oracle as O
+    T, B = hg.shape[0], hg.shape[1]
+    sep = np.abs(hx - ox).max(-1)                              # [T + 1, B, K]
+    onset = np.full(sep.shape[1:], T + 1, dtype=int)            # first t with x_{t+1} apart
+    for t in range(T, 0, -1):
+        onset[sep[t] > onset_tol] = t - 1
+    todo = sorted(zip(*np.nonzero(onset <= T - 1)), key=lambda bi: onset[bi])
+    cache = {}
+
+    def at_step(t):
+        if t not in cache:
+            hip_idx = r.repulsion_loss(torch.from_numpy(hx[t]), want_idx=True)[1].cpu().numpy()     # exact 5-NN: what the kernel uses
+            ref_idx = O.knn_point(5, torch.from_numpy(hx[t])).numpy()
+            g1 = _oracle_grad(MO, w, hx[t], cond, loss_batch)
+            g2 = _oracle_grad(MO, w, hx[t], cond, loss_batch, hip_idx)
+            cache[t] = (g1, g2, hip_idx, ref_idx)
+        return cache[t]
+
+    np.testing.assert_allclose(_oracle_grad(MO, w, ox[0], cond, loss_batch), og[0], rtol=0, atol=1e-6 * np.abs(og[0]).max())
+    reasons, unexplained = {}, []
+    for b, i in todo:
+        t = int(onset[b, i])
+        g1, g2, hip_idx, ref_idx = at_step(t)
+        noise = g_noise * np.abs(og[t, b]).max()
+        d_impl = np.abs(hg[t, b, i] - g1[b, i]).max()
+        d_idx = np.abs(hg[t, b, i] - g2[b, i]).max()
+        d_sens = np.abs(g1[b, i] - og[t, b, i]).max()
+        a = int(np.abs(hx[t + 1, b, i] - ox[t + 1, b, i]).argmax())
+        why = None
+        if d_idx <= noise < d_impl:
+            who = [j for j in range(hip_idx.shape[1]) if (j == i or i in hip_idx[b, j] or i in ref_idx[b, j])
+                   and set(hip_idx[b, j].tolist()) != set(ref_idx[b, j].tolist())]
+            why = "B: same positions, gradients %.1e apart (of max), %.1e with the build's 5-NN sets in the oracle; sets differ for point(s) %s" % (
+                d_impl / noise * g_noise, d_idx / noise * g_noise, who[:4])
+        elif d_impl <= noise and d_sens > noise:
+            nb = set(hip_idx[b, i].tolist()) | set(ref_idx[b, i].tolist()) | {j for j in range(hip_idx.shape[1]) if i in hip_idx[b, j] or i in ref_idx[b, j]}
+            early = [j for j in nb if onset[b, j] < t and (b, j) in reasons]
+            if early:
+                why = "C: neighbour %d separated at step %d; implementations agree at the build's positions to %.1e" % (
+                    early[0], onset[b, early[0]], d_impl / noise * g_noise)
+            else:
+                why = "S: implementations agree at the build's positions to %.1e; the oracle's gradient moves by %.1e between positions %.1e apart" % (
+                    d_impl / noise * g_noise, d_sens / noise * g_noise, sep[t, b].max())
+        elif d_impl <= noise:
+            hist = max(np.abs(og[:t + 1, b, i, a]).max(), np.abs(hg[:t + 1, b, i, a]).max())
+            if hist <= 10.0 * noise:
+                why = "A: all gradients agree to %.1e; |g| <= %.1e of max over steps 0..%d" % (max(d_impl, d_sens) / noise * g_noise, hist / noise * g_noise, t)
+        else:
+            cond_b = {k: v[b:b + 1] for k, v in cond.items()} if isinstance(cond, dict) else cond[b:b + 1]
+            jumps = _oracle_kink_jumps(MO, w, hx[t, b, i], cond_b, loss_batch)
+            miss = np.abs(jumps - (hg[t, b, i] - g1[b, i])[None]).max(-1).min()
+            print("  %s: cloud %d point %d step %d: implementations %.1e apart at identical positions; nearest oracle jump under a nudge misses it by %.1e (of max)" % (
+                tag, b, i, t, d_impl / noise * g_noise, miss / noise * g_noise))
+            if miss <= 3.0 * noise:
+                why = "R: same positions and neighbour sets, gradients %.1e apart (of max); the oracle's own occupancy gradient makes that jump (to %.1e) under a nudge of <= 512 ulps" % (
+                    d_impl / noise * g_noise, miss / noise * g_noise)
+        if why is None:
+            unexplained.append((int(b), int(i), t, a, "d_impl %.1e d_idx %.1e d_sens %.1e (of max)" % (
+                d_impl / noise * g_noise, d_idx / noise * g_noise, d_sens / noise * g_noise)))
+        else:
+            reasons[(b, i)] = (t, why)
+    final_off = np.linalg.norm(hx[-1] - ox[-1], axis=-1) > 1e-3
+    kinds_all, kinds_off = {}, {}
+    for (b, i), (t, why) in reasons.items():
+        kinds_all[why[0]] = kinds_all.get(why[0], 0) + 1
+        if final_off[b, i]:
+            kinds_off[why[0]] = kinds_off.get(why[0], 0) + 1
+            print("  %s: cloud %d point %4d separates at step %d - %s" % (tag, b, i, t, why))
+    print("%s: %d of %d points separate by > %.0e in %d steps %s; %d of them end beyond 1e-3 %s; unexplained: %d" %
+          (tag, len(todo), sep[0].size, onset_tol, T, kinds_all, int(final_off.sum()), kinds_off, len(unexplained)))
+    for u in unexplained:
+        print("  UNEXPLAINED", tag, u)
+    assert not unexplained, (tag, len(unexplained))
+    return reasons
+
+
+def _ulp_floor(MO, w, init, cond_fn, iterations, loss_batch, ref_out):
+    """How many points of the ORACLE end beyond 1e-3 of its own run when every input coordinate moves by one ulp (three sign
+    patterns): the sensitivity floor any other f32 implementation is measured against."""
+    counts = []
+    for seed in (0, 1, 2, 3, 4):
+        g = torch.Generator().manual_seed(100 + seed)
+        up = torch.rand(init.shape, generator=g) < 0.5
+        pert = torch.where(up, torch.nextafter(init, torch.full_like(init, 2.0)), torch.nextafter(init, torch.full_like(init, -2.0)))
+        out = cond_fn(pert)
+        counts.append(int((np.linalg.norm(out - ref_out, axis=-1) > 1e-3).sum()))
+    return counts
+
+
+
 def _oracle_restore_from_hip_draws(restorer, oracle_weights, clouds, iterations, sor=True):
     """HIP SOR + prepare (its own counter-based draws), then BOTH sides restore from those draws:
     returns (hip_out, oracle_out, prep, keep)."""
@@ -677,13 +863,39 @@ def _oracle_restore_from_hip_draws(restorer, oracle_weights, clouds, iterations,
     t = prep["t_per_cloud"].cpu().tolist()
     planes_hip = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
     hip = restorer.optimize_points(prep["init"], planes_hip, rep_weight=500.0, iterations=iterations)
-    outs = []
+    outs, planes_ref = [], []
     for b in range(len(clouds)):                     # ragged subsets: the oracle encodes cloud by cloud
         sel_b = prep["sel"][b:b + 1, :t[b]].cpu()
         planes_b = O.encode_inputs(oracle_weights, sel_b)
+        planes_ref.append(planes_b)
         outs.append(O.optimize_points(oracle_weights, prep["init"][b:b + 1].cpu(), planes_b, rep_weight=500.0,
                                       iterations=iterations, loss_batch=len(clouds)))
+    prep["_planes_hip"], prep["_planes_ref"] = planes_hip, planes_ref
     return hip.cpu().numpy(), torch.cat(outs).numpy(), prep, keep
+
+
+def _attribute_config(restorer, oracle_weights, prep, hip, iterations, tag):
+    """Every point of a config #3 / #5 run that leaves the oracle's trajectory is attributed (see the block comment above):
+    the optimiser on the build's planes against the oracle fed with the same planes (what the end-to-end figures above add is
+    the two encoders' 1e-5 difference in the planes - the same mechanisms with a wider noise band), and the count of points
+    beyond 1e-3 held against the oracle's own one-ulp sensitivity.  Returns (points beyond 1e-3, the ulp floor)."""
+    from oracle import convonet_oracle as O
+    import ifdefense_amd as I
+    B, T = hip.shape[0], iterations + 1
+    init = prep["init"]
+    hx, hg, last = _hip_trace(restorer, init, prep["_planes_hip"], T, B)
+    assert np.array_equal(restorer.normalize_batch_pc(last).cpu().numpy(), hip)          # launch per step == one launch, bitwise
+    pd = I.planes_from_channel_last(prep["_planes_hip"].cpu())
+    ox, og = _oracle_trace(O, oracle_weights, init.cpu(), pd, T, B)
+    _attribute_separations(restorer, O, oracle_weights, pd, B, hx, hg, ox, og, tag + " (optimiser alone)")
+    n_opt = int((np.linalg.norm(hx[-1] - ox[-1], axis=-1) > 1e-3).sum())
+    floor = _ulp_floor(O, oracle_weights, init.cpu(),
+                       lambda q: O.optimize_points(oracle_weights, q, pd, rep_weight=500.0, iterations=iterations, loss_batch=B,
+                                                   normalize=False).numpy(), iterations, B, ox[-1])
+    print("%s: points beyond 1e-3 after %d steps, optimiser alone: build vs oracle %d, oracle vs its own 1-ulp-perturbed runs %s" %
+          (tag, T, n_opt, floor))
+    assert n_opt <= max(floor) + 5, (tag, n_opt, floor)
+    return n_opt, floor
 
 
 def test_config3_knn_attack_like_clouds(restorer, golden, oracle_weights):
@@ -703,6 +915,7 @@ def test_config3_knn_attack_like_clouds(restorer, golden, oracle_weights):
     print("config #3, 10 steps: max %.2e, median %.2e, points > 1e-3: %d of %d" % (d.max(), np.median(d), (d > 1e-3).sum(), d.size))
     # measured (round 3): 1 of 4096 points beyond 1e-3 (1.26e-3), median 3.2e-7
     assert (d > 1e-3).sum() <= 2 and np.median(d) < 1e-6 and d.max() < 2.6e-3, (d.max(), np.median(d), int((d > 1e-3).sum()))
+    _attribute_config(restorer, oracle_weights, prep, hip, 9, "config #3")
     # 150 steps on the clustered clouds: lists + individual refreshes == exact scan, bit for bit
     planes = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
     a = restorer.optimize_points(prep["init"], planes, rep_weight=500.0, iterations=150, normalize=False)
@@ -735,6 +948,7 @@ def test_config5_sparse_inputs(restorer, golden, oracle_weights):
             max_off, max_d = {(824, True): (0, 6e-4), (824, False): (0, 3e-4), (256, True): (26, 3.2e-2), (256, False): (4, 4e-3)}[
                 (clouds.shape[1], sor)]
             assert (d > 1e-3).sum() <= max_off and np.median(d) < 1e-6 and d.max() < max_d, (clouds.shape, sor, d.max(), int((d > 1e-3).sum()))
+            _attribute_config(restorer, oracle_weights, prep, hip, 9, "config #5 K=%d sor=%s" % (clouds.shape[1], sor))
 
 
 def test_unet_matches_reference_and_is_batch_invariant(restorer, golden):
@@ -1020,6 +1234,15 @@ def test_onet_config1_pipeline_16_clouds(onet):
     print("ONet config #1, 10 steps, 16 clouds: max %.2e median %.2e, points > 1e-3: %d of %d" %
           (d.max(), np.median(d), (d > 1e-3).sum(), d.size))
     assert (d > 1e-3).mean() < 1e-3 and np.median(d) < 1e-5
+    # every separating point attributed (block comment above _oracle_trace), the optimiser alone on the build's latent codes
+    hx, hg, _ = _hip_trace(onet, prep["init"], c, 10, 16)
+    ox, og = _oracle_trace(OO, ow, prep["init"].cpu(), c.cpu(), 10, 16)
+    _attribute_separations(onet, OO, ow, c.cpu(), 16, hx, hg, ox, og, "ONet config #1 (optimiser alone)")
+    n_opt = int((np.linalg.norm(hx[-1] - ox[-1], axis=-1) > 1e-3).sum())
+    floor = _ulp_floor(OO, ow, prep["init"].cpu(), lambda q: OO.optimize_points(ow, q, c.cpu(), rep_weight=500.0, iterations=9,
+                                                                               normalize=False).numpy(), 9, 16, ox[-1])
+    print("ONet config #1: points beyond 1e-3 after 10 steps: build vs oracle %d, oracle vs its 1-ulp-perturbed runs %s" % (n_opt, floor))
+    assert n_opt <= max(floor) + 5, (n_opt, floor)
     args = I.DefenseArgs(iterations=50, input_npoint=300, seed=21)
     full = I.defend_point_cloud(onet, clouds, args)
     assert full.shape == (16, 1024, 3) and np.isfinite(full).all()
