@@ -261,6 +261,23 @@ def extras(dev):
             "ms_per_round": round(e0.elapsed_time(e1), 1), "vs_trained_families": round(e0.elapsed_time(e1) / (ms / 2.0), 3),
             "list_rebuilds_per_cloud": round(ca["knn_rebuilds"] / 8.0 / 64, 2),
             "what": "64 airplane clouds (one partial round, one workgroup per cloud) on the same checkpoint"}
+        # all seven families in ONE launch (what a real file looks like: the slowest clouds of a round set its length)
+        xm = torch.from_numpy(pool[:n]).to(dev)
+        pm = r.prepare(xm, r.sor(xm), seed=1234)
+        plm = r.encode_inputs(pm["sel"], pm["t_per_cloud"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r.optimize_points(pm["init"], plm, rep_weight=500.0, iterations=ITERATIONS, loss_batch=lb, normalize=False)
+        e1.record()
+        torch.cuda.synchronize()
+        cm = r.counters()
+        msm = e0.elapsed_time(e1)
+        out["trained_like_mixed"] = {
+            "value": round(n / (msm * 1e-3), 1), "unit": "clouds/s (optimiser launch only)",
+            "roofline_frac": round(FLOP_DENSE_PER_CLOUD * n / (msm * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "list_rebuilds_per_cloud": round(cm["knn_rebuilds"] / 8.0 / n, 2),
+            "what": "the same launch with all SEVEN bench families interleaved (%d clouds, one in seven an airplane the "
+                    "checkpoint never saw): two whole rounds whose length the slowest clouds set" % n}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["trained_like"] = {"error": str(e)[:200]}
@@ -309,6 +326,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="serial passes (no second stream for the next pass's pre-processing)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements (reference-style unfused "
                     "GPU baseline, ONet-Opt, ONet-Mesh) that ride along in the N = 1 line")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: initialise the process group (gloo on a CPU host), shard the clouds, push a placeholder "
+                         "of every rank's shard through the real gather, print the JSON line with value null - checks the launch "
+                         "line, the sharding arithmetic and the line's fields for any --gpus N without N GPUs")
     ap.add_argument("--workload", choices=("convonet-opt", "onet-opt"), default="convonet-opt",
                     help="convonet-opt = the BASELINE metric (default); onet-opt = the ONet-Opt decoder variant "
                          "(BASELINE config #1 model, SURVEY N4) at 500 iterations - an extra line, not the headline")
@@ -321,14 +342,31 @@ def main():
     from ifdefense_amd import dist as D
     import torch.distributed as dist
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env("gloo" if a.dry_run else None)
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (a.gpus, world))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
     total = a.clouds * world if a.scaling == "weak" else a.clouds
     lo, hi, per = D.shard_range(total, rank, world)
+    if a.dry_run:
+        # every rank contributes a placeholder of its shard's shape, stamped with the global cloud indices it owns: the
+        # gathered array must be 0 ... total - 1 in order on every rank (the sharding helper + the one collective of the path)
+        mine = torch.arange(lo, hi, dtype=torch.float32)[:, None, None].expand(hi - lo, 1, 3).contiguous()
+        full = D.gather_shards(mine, total, per)
+        ok = full.shape == (total, 1, 3) and bool(torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32)))
+        if rank == 0:
+            print(json.dumps({
+                "metric": "restored clouds/sec (1024-pt ModelNet40, %s 500 iters)" % ("ONet-Opt" if onet else "ConvONet-Opt"),
+                "value": None, "unit": "clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+                "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "dry_run": True, "gather_ok": ok,
+                "config": {"clouds_per_gpu": per, "clouds_total": total, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
+                           "parallelism": "shard%d+allgather" % world, "shard_of_rank0": [lo, hi]}}))
+        D.shutdown()
+        if not ok:
+            raise SystemExit("dry run: the gathered array is not the concatenation of the ranks' shards")
+        return
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
     my_clouds = synth_clouds(hi - lo, start=lo)                         # every rank synthesises only its own shard
     x = torch.from_numpy(my_clouds).to(dev)                             # resident in HBM before timing
     if onet:
@@ -428,6 +466,17 @@ def main():
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
             "gather_ms": round(sum(g0.elapsed_time(g1) for g0, g1 in gev) / max(1, len(gev)), 3),
         }
+        if world == 1 and not onet and not a.no_extras and not a.no_overlap:
+            # BASELINE configs[1] is ONE file: the literal single-file case (no later pass whose pre-processing could ride on
+            # the optimiser's tail), three serial passes, driver-timed in every run
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in I.defend_stream(r, [x] * 3, args, bases=[lo] * 3, totals=[total] * 3, overlap=False):
+                torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / 3
+            res["single_file"] = {"value": round(total / dt1, 2), "unit": "clouds/s", "ms_per_file": round(dt1 * 1e3, 2),
+                                  "what": "one 2468-cloud file at a time (--no-overlap semantics, a device synchronisation "
+                                          "after every file), mean of 3: BASELINE configs[1] taken literally"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(my_clouds, onet=onet, full_run_clouds=0 if onet else 4)
         if world == 1 and not onet and not a.no_extras:

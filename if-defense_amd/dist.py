@@ -42,6 +42,12 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
+            n_dev = torch.cuda.device_count()
+            if local >= n_dev:
+                raise RuntimeError(
+                    "LOCAL_RANK=%d but this node shows %d GPU(s) to the process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES=%s): "
+                    "one process per GPU - launch with --nproc-per-node <= %d, or make more devices visible" %
+                    (local, n_dev, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "unset")), max(n_dev, 1)))
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)      # bind the RCCL communicator (and barrier()) to this rank's GPU
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)

@@ -13,6 +13,11 @@ has its own fixtures), decoder logits and input gradient at the initial points (
 x_next, losses) at steps 0, 9, 99 (G4 / G7) and the function's normalised return value after 100 steps.
 Writes tests/golden/convonet_golden_trained.npz.  Build container only.
 
+Round 4 (`--long`): the same eight clouds, draws and planes through a full 500-iteration call of the reference's
+optimize_points, (x, grad, exp_avg, exp_avg_sq, x_next, losses) at steps 299 and 499 (Adam t = 300, 500: the converged regime,
+where optimised points pair up on the surface) and the function's normalised return value after 501 steps ->
+tests/golden/convonet_golden_trained_long.npz.  The short fixture is not rewritten by `--long`.
+
     python tests/golden/make_golden_trained.py
 """
 import os
@@ -79,6 +84,27 @@ def main():
     lg = model.decode((torch.rand(8, 20000, 3) - 0.5) * 1.1, planes).logits
     print("field: fraction of the cube above logit(0.2): %.3f, logit range %.1f ... %.1f" %
           (float((torch.sigmoid(lg) > 0.2).float().mean()), float(lg.min()), float(lg.max())))
+    if "--long" in sys.argv:
+        # the same init / planes (the draws above are seeded): must reproduce the short fixture's inputs bit for bit
+        old = np.load(os.path.join(HERE, "convonet_golden_trained.npz"))
+        assert np.array_equal(old["init_points"], out["init_points"]) and np.array_equal(old["planes_f16"], out["planes_f16"])
+        assert np.array_equal(old["traj99_x_next"], out["traj99_x_next"]), "the 100-step trajectory did not reproduce"
+        rec = (299, 499)
+        final, snaps = RD.run_optimize(ns, init, planes, iterations=499, record=rec)
+        lo = {"init_points": out["init_points"]}
+        for i in rec:
+            for k in ("x", "g", "m", "v", "x_next"):
+                lo[f"traj{i}_{k}"] = snaps[i][k].numpy()
+            lo[f"traj{i}_loss"] = np.array([snaps[i]["occ"], snaps[i]["rep"]], np.float64)
+        lo["out501_normalised"] = final
+        with torch.no_grad():
+            s2 = torch.sigmoid(model.decode(snaps["final_unnormalised"], planes).logits)
+        lo["occ_prob_final"] = s2.numpy()
+        print("after 501 steps: occupancy probability mean %.3f (|p - 0.2| %.4f)" % (float(s2.mean()), float((s2 - 0.2).abs().mean())))
+        path = os.path.join(HERE, "convonet_golden_trained_long.npz")
+        np.savez_compressed(path, **lo)
+        print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+        return
     path = os.path.join(HERE, "convonet_golden_trained.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))

@@ -1651,6 +1651,13 @@ def test_rccl_path_under_torchrun(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "shard1+allgather"
     assert 0.05 < line["roofline"]["frac"] < 1.0
+    # --scaling strong (BASELINE configs #3 / #5: ONE array over the ranks) through the same launch line
+    r = launch(["bench.py", "--gpus", "1", "--clouds", "70", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+                "--scaling", "strong"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["clouds_total"] == 70 and line["config"]["clouds_per_gpu"] == 70
 
 
 @pytest.mark.parametrize("k", [6, 7, 16, 17, 33, 48, 49, 100, 333, 777, 1023])
@@ -1741,6 +1748,9 @@ def trained():
     z = np.load(os.path.join(here, "trained_like_f16.npz"))
     w = {k: z[k].astype(np.float32) for k in z.files}
     f = dict(np.load(os.path.join(here, "convonet_golden_trained.npz")))
+    long = np.load(os.path.join(here, "convonet_golden_trained_long.npz"))       # Adam t = 300 / 500 of a 500-iteration reference run
+    assert np.array_equal(long["init_points"], f["init_points"])
+    f.update({k: long[k] for k in long.files if k != "init_points"})
     planes = {pl: torch.from_numpy(f["planes_f16"][:, i].astype(np.float32)) for i, pl in enumerate(PL)}
     r = I.Restorer(I.weights.pack_state_dict(w), device="cuda:0")
     yield r, f, planes, w
@@ -1757,7 +1767,8 @@ def test_trained_like_decoder_and_hot_gradient(trained):
     thr = float(np.log(0.2 / 0.8))
     assert ((f["dec_logits"] > thr).any(1) & (f["dec_logits"] < thr).any(1)).all()
     from oracle import convonet_oracle as O
-    for t in (0, 9, 99):                                           # P1 + the hot tile's gradient, Adam t = 1, 10, 100, B = 8
+    quirks = {}
+    for t in (0, 9, 99, 299, 499):                                 # P1 + the hot tile's gradient, Adam t = 1, 10, 100, 300, 500, B = 8
         x_next, g, v1 = _hot_gradient(r, f, planes, t)
         g_ref = f[f"traj{t}_g"].astype(np.float64)
         # Near-coincident points (1.5e-4 apart at t = 100: the optimisation pulls pairs together on the surface) are below
@@ -1777,11 +1788,19 @@ def test_trained_like_decoder_and_hot_gradient(trained):
         flips = int(((np.abs(x_next - f[f"traj{t}_x_next"]) > 1e-6).any(-1) & ~quirk).sum())
         print("trained-like t=%d: gradient rel. error %.2e, coordinates off by > 1e-6: %d of %d; %d points below the resolution of "
               "the reference's kNN left out" % (t + 1, eg, flips, x_next.size, int(quirk.sum())))
-        assert eg < 5e-6 and flips == 0 and quirk.sum() <= 4, (t, eg, flips, int(quirk.sum()))
+        quirks[t + 1] = int(quirk.sum())
+        close = int((np.sqrt(d2.min(-1)) < 2e-4).sum())
+        print("   points with another point closer than 2e-4: %d of %d" % (close, d2.shape[0] * d2.shape[1]))
+        assert eg < 5e-6 and flips == 0, (t, eg, flips)
+    # The quirk grows with the iteration count - converged points pair up on the surface - and stays a fringe effect:
+    # measured (round 4) 0 / 0 / 4 / 10 / 14 points of 8192 at Adam t = 1 / 10 / 100 / 300 / 500.
+    print("points below the resolution of the reference's kNN, by Adam t:", quirks)
+    assert quirks[1] == 0 and quirks[10] == 0 and quirks[100] <= 4 and quirks[300] <= 24 and quirks[500] <= 32, quirks
+    assert quirks[500] >= quirks[100]
 
 
 def test_trained_like_free_running_and_losses(trained):
-    r, f, planes, _ = trained
+    r, f, planes, w_np = trained
     init = torch.from_numpy(f["init_points"])
     out10 = r.optimize_points(init, planes, rep_weight=500.0, iterations=9, normalize=False).cpu().numpy()
     d = np.linalg.norm(out10 - f["traj9_x_next"], axis=-1)         # P2: 10 free-running steps
@@ -1796,8 +1815,21 @@ def test_trained_like_free_running_and_losses(trained):
     # this is distributional - the bulk of the points agrees closely, the surface is the same
     out = r.optimize_points(init, planes, rep_weight=500.0, iterations=99).cpu().numpy()
     d = np.linalg.norm(out - f["out100_normalised"], axis=-1)
-    print("trained-like 100 steps + normalisation: median %.2e, points > 1e-3: %.1f %%" % (np.median(d), 100.0 * (d > 1e-3).mean()))
-    assert np.median(d) < 1e-4
+    # ... and the fraction beyond 1e-3 is held against the reference's own sensitivity: the oracle (the reference's op
+    # sequence) from initial points moved by one ulp, against the same fixture
+    from oracle import convonet_oracle as O
+    ow = O.to_torch(w_np)
+    floor = []
+    for seed in (0, 1):
+        g = torch.Generator().manual_seed(200 + seed)
+        up = torch.rand(init.shape, generator=g) < 0.5
+        pert = torch.where(up, torch.nextafter(init, torch.full_like(init, 2.0)), torch.nextafter(init, torch.full_like(init, -2.0)))
+        o = O.optimize_points(ow, pert, planes, rep_weight=500.0, iterations=99).numpy()
+        floor.append(float((np.linalg.norm(o - f["out100_normalised"], axis=-1) > 1e-3).mean()))
+    frac = float((d > 1e-3).mean())
+    print("trained-like 100 steps + normalisation: median %.2e, points > 1e-3: %.2f %% (the oracle from 1-ulp-perturbed inputs: %s %%)" %
+          (np.median(d), 100.0 * frac, ["%.2f" % (100.0 * x) for x in floor]))
+    assert np.median(d) < 1e-4 and frac <= max(floor) + 0.003, (frac, floor)
     np.testing.assert_allclose(np.linalg.norm(out, axis=-1).max(axis=1), 1.0, rtol=1e-6)
 
 

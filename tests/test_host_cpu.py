@@ -337,3 +337,55 @@ def test_cli_compute_failure_on_one_rank_stops_every_rank_before_the_gather(tmp_
     assert (d / "ConvONet-Opt" / "convonet_opt-a.npz").exists()          # the first file went through before the failure
     assert not (d / "ConvONet-Opt" / "convonet_opt-c.npz").exists()
     assert time.time() - t0 < 120, "the ranks did not stop promptly"
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launch_line_dry_run_for_2_4_8_ranks(scaling):
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
+    without N GPUs: `--dry-run` creates the process group (gloo), shards the clouds like the timed path does, pushes a
+    placeholder of every rank's shard through the path's one collective and prints the JSON line with value null.  Checked
+    for N = 2, 4, 8 in both scalings: the gathered array is the concatenation of the shards on every rank, and
+    clouds_total / clouds_per_gpu / parallelism are what the scaling mode promises (weak: 2468 per rank; strong: ONE
+    2468-cloud array - BASELINE configs #3 / #5 - over the ranks, the last shard shorter).  The reference shards its attack
+    scripts the same way (baselines/attack_scripts/targeted_knn_attack.py:97-128)."""
+    import json
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for n in (2, 4, 8):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs.append((n, subprocess.Popen(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+             "--master-port", str(port), "bench.py", "--gpus", str(n), "--scaling", scaling, "--dry-run"],
+            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root,
+            env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))))
+    for n, p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, (n, out[-2000:], err[-3000:])
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, (n, out)                               # rank 0 prints ONE line
+        j = json.loads(lines[0])
+        assert j["dry_run"] and j["gather_ok"] and j["value"] is None and j["n_gpus"] == n and j["scaling"] == scaling
+        c = j["config"]
+        assert c["parallelism"] == "shard%d+allgather" % n
+        if scaling == "weak":
+            assert c["clouds_per_gpu"] == 2468 and c["clouds_total"] == 2468 * n and c["shard_of_rank0"] == [0, 2468]
+        else:
+            per = -(-2468 // n)
+            assert c["clouds_total"] == 2468 and c["clouds_per_gpu"] == per and c["shard_of_rank0"] == [0, per]
+
+
+def test_init_from_env_rejects_a_local_rank_without_a_gpu(monkeypatch):
+    """One process per GPU: a rank whose LOCAL_RANK has no device behind it (more ranks than visible GPUs) must say so, not
+    die inside torch.cuda.set_device / the RCCL communicator."""
+    from ifdefense_amd import dist as D
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(RuntimeError, match="LOCAL_RANK=3 but this node shows 1 GPU"):
+        D.init_from_env("nccl")
