@@ -450,8 +450,18 @@ __device__ __forceinline__ void mfma16(const WFrag& f, const f32x8& in, Acc2& ac
 // interleave pattern of one region: 4 x { 4 MFMAs, 4 NV VALU, 4 ND DS reads }, then close the region.  (An f32 MFMA and a
 // vector instruction exclude each other on the SIMD and every switch between the two kinds costs issue cycles, so they
 // alternate in groups, not one by one.)
+// -DIFD_EXTRA_VALU=<n>: n dummy vector instructions per software-pipeline region (measurement only: what ONE more vector
+// instruction next to the MFMA stream costs in the real kernel - scripts/ab_bench.sh)
+#ifndef IFD_EXTRA_VALU
+#define IFD_EXTRA_VALU 0
+#endif
 template <int NV, int ND>
 __device__ __forceinline__ void region_end() {
+    if (IFD_EXTRA_VALU > 0) {
+        int dummy = 0;
+#pragma unroll
+        for (int k = 0; k < IFD_EXTRA_VALU; ++k) asm volatile("v_add_u32 %0, 1, %0" : "+v"(dummy));
+    }
     constexpr int GROUP = 4;         // 2: 418 k, 4 / 8: 412 k, 16: 413 k cycles per step (one by one: 428 k)
 #pragma unroll
     for (int i = 0; i < 16 / GROUP; ++i) {

@@ -1758,7 +1758,7 @@ def trained():
 
 
 def test_trained_like_decoder_and_hot_gradient(trained):
-    r, f, planes, _ = trained
+    r, f, planes, w_np = trained
     p = torch.from_numpy(f["init_points"])
     logits, grad = r.decode(p, planes, want_grad=True)
     assert _rel(logits.cpu().numpy(), f["dec_logits"]) < 1e-5
@@ -1767,35 +1767,44 @@ def test_trained_like_decoder_and_hot_gradient(trained):
     thr = float(np.log(0.2 / 0.8))
     assert ((f["dec_logits"] > thr).any(1) & (f["dec_logits"] < thr).any(1)).all()
     from oracle import convonet_oracle as O
-    quirks = {}
+    ow = O.to_torch(w_np)
+    quirks, nsets = {}, {}
     for t in (0, 9, 99, 299, 499):                                 # P1 + the hot tile's gradient, Adam t = 1, 10, 100, 300, 500, B = 8
         x_next, g, v1 = _hot_gradient(r, f, planes, t)
         g_ref = f[f"traj{t}_g"].astype(np.float64)
-        # Near-coincident points (1.5e-4 apart at t = 100: the optimisation pulls pairs together on the surface) are below
-        # the resolution of the reference's kNN: its expanded-form distance |a|^2 + |b|^2 - 2ab carries ~1e-7 of absolute
-        # noise, so for such a pair column 0 of its top-6 is the OTHER point, "self" gets dropped as a neighbour's stand-in
-        # (pn_utils.py:81-82) and the pair's repulsion term is missing from the reference's own gradient.
-        # The kernel's 5-NN is exact by construction.  Those points - rows of the reference's index tensor that contain
-        # their own index, and their partners - are counted and left out; everything else is held to 5e-6.
+        gmax = np.abs(g_ref).max()
         x = torch.from_numpy(f[f"traj{t}_x"])
-        idx = O.knn_point(5, x).numpy()
-        own = (idx == np.arange(idx.shape[1])[None, :, None]).any(-1)                     # [B,K]
-        d2 = torch.cdist(x.double(), x.double()).numpy() + np.eye(idx.shape[1])[None] * 1e9
-        quirk = own.copy()
-        for b, k in zip(*np.nonzero(own)):
-            quirk[b, d2[b, k].argmin()] = True
-        eg = (np.abs(g - g_ref).max(-1) * ~quirk).max() / np.abs(g_ref).max()
-        flips = int(((np.abs(x_next - f[f"traj{t}_x_next"]) > 1e-6).any(-1) & ~quirk).sum())
-        print("trained-like t=%d: gradient rel. error %.2e, coordinates off by > 1e-6: %d of %d; %d points below the resolution of "
-              "the reference's kNN left out" % (t + 1, eg, flips, x_next.size, int(quirk.sum())))
-        quirks[t + 1] = int(quirk.sum())
-        close = int((np.sqrt(d2.min(-1)) < 2e-4).sum())
-        print("   points with another point closer than 2e-4: %d of %d" % (close, d2.shape[0] * d2.shape[1]))
-        assert eg < 5e-6 and flips == 0, (t, eg, flips)
-    # The quirk grows with the iteration count - converged points pair up on the surface - and stays a fringe effect:
-    # measured (round 4) 0 / 0 / 4 / 10 / 14 points of 8192 at Adam t = 1 / 10 / 100 / 300 / 500.
-    print("points below the resolution of the reference's kNN, by Adam t:", quirks)
-    assert quirks[1] == 0 and quirks[10] == 0 and quirks[100] <= 4 and quirks[300] <= 24 and quirks[500] <= 32, quirks
+        # Where the two gradients differ at all, it is the NEIGHBOUR CHOICE and nothing else: the reference ranks candidates by
+        # the expanded form |a|^2 + |b|^2 - 2ab in f32 (~1e-7 of absolute noise; pn_utils.py:76-82), the kernel by exact
+        # differences.  On the converged surface optimised points pair up (1.5e-4 apart and closer), and then (i) 5th / 6th
+        # candidates swap, and (ii) column 0 of the reference's top-6 - which it drops as "self" (pn_utils.py:81-82) - is the
+        # OTHER point of a pair, so that self stays in as a neighbour and the pair's term is missing from the reference's own
+        # gradient.  Demonstrated by substitution: the reference's objective evaluated by autograd at the same
+        # points with the kernel's 5-NN sets must reproduce the kernel's gradient at EVERY point (no exclusions), and the
+        # points where the reference's own gradient differs must all be touched by a differing set.
+        ref_idx = O.knn_point(5, x).numpy()
+        hip_idx = r.repulsion_loss(x, want_idx=True)[1].cpu().numpy()
+        g_sub = _oracle_grad(O, ow, x.numpy(), planes, 8, hip_idx).astype(np.float64)
+        e_sub = np.abs(g - g_sub).max() / gmax
+        differ = np.array([[set(ref_idx[b, k].tolist()) != set(hip_idx[b, k].tolist()) for k in range(1024)] for b in range(8)])
+        touched = differ.copy()
+        for b, k in zip(*np.nonzero(differ)):
+            for j in set(ref_idx[b, k].tolist()) ^ set(hip_idx[b, k].tolist()):
+                touched[b, j] = True
+        off = np.abs(g - g_ref).max(-1) > 5e-6 * gmax
+        own = (ref_idx == np.arange(1024)[None, :, None]).any(-1)                  # the "self" quirk (ii)
+        flips = (np.abs(x_next - f[f"traj{t}_x_next"]) > 1e-6).any(-1)
+        print("trained-like t=%d: gradient vs the reference with the kernel's neighbour sets %.2e of max (every point); the reference's own "
+              "gradient differs at %d points, all touched by one of %d differing 5-NN sets (%d of them the self-column quirk); "
+              "coordinates of x_next off by > 1e-6: %d, all at such points" % (t + 1, e_sub, int(off.sum()), int(differ.sum()), int(own.sum()),
+                                                                               int(flips.sum())))
+        assert e_sub < 5e-6, (t, e_sub)
+        assert not (off & ~touched).any() and not (flips & ~touched).any(), (t, int((off & ~touched).sum()), int((flips & ~touched).sum()))
+        quirks[t + 1], nsets[t + 1] = int(own.sum()), int(differ.sum())
+    # Both effects grow with the iteration count - converged points pair up on the surface - and stay a fringe: measured
+    # (round 4) at Adam t = 1 / 10 / 100 / 300 / 500, of 8192 points
+    print("reference 5-NN sets that differ from the exact ones, by Adam t: %s; of which self-column quirk: %s" % (nsets, quirks))
+    assert nsets[1] == 0 and nsets[10] == 0 and nsets[100] <= 8 and nsets[300] <= 40 and nsets[500] <= 60, nsets
     assert quirks[500] >= quirks[100]
 
 
