@@ -305,8 +305,15 @@ def extras(dev):
         t0 = time.perf_counter()
         r.mesh_sample(c[:64], threshold=thr)
         torch.cuda.synchronize()
-        out["onet_mesh"] = {"value": round(64 / (time.perf_counter() - t0), 1), "unit": "clouds/s",
-                            "what": "ifd_onet_mesh_sample, 64 clouds, 32 -> 128 MISE grid, iso-surface at the field's median"}
+        dtm = time.perf_counter() - t0
+        km = r.counters()
+        flop_m = km["mesh_points"] * 2 * (10 * 256 * 256 + 4 * 256)        # decoder forward per evaluated grid point
+        out["onet_mesh"] = {"value": round(64 / dtm, 1), "unit": "clouds/s",
+                            "grid_points_per_cloud": int(km["mesh_points"] / 64), "mise_rounds": int(km["mesh_rounds"]),
+                            "roofline_frac": round(flop_m / dtm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                            "what": "ifd_onet_mesh_sample, 64 clouds, 32 -> 128 MISE grid, iso-surface at the field's median; "
+                                    "roofline_frac = decoder FLOPs of the evaluated grid points / WHOLE-path time / f32-MFMA peak "
+                                    "(onet_grid_eval_kernel alone: profiles/r04_onet_mesh_kernel_stats.txt)"}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["onet"] = {"error": str(e)[:200]}

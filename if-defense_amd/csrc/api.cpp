@@ -90,6 +90,7 @@ struct ifd_ctx {
     ifd_config cfg{};
     std::vector<float> w;          // host copy, canonical order
     float* d_dec_img = nullptr;    // decoder parameter image (ifd_device.h layout)
+    float* d_dec_img_opt = nullptr;// ... the persistent optimiser's copy: fc_0 / fc_1 / fc_out scaled by 2^RELU_K (ifd_device.h)
     float* d_w = nullptr;          // the whole canonical weight vector on the device (encoder kernels index it)
     EncPointOffsets eo{};
     float* d_unet = nullptr;       // re-packed U-Net weights ([tap][Cin][Cout])
@@ -149,7 +150,7 @@ DeviceGuard::DeviceGuard(const ifd_ctx* ctx) {
     if (!ifd_device_guard_.ok) return fail(ctx, IFD_ERR_HIP, "cannot make the context's device current")
 
 // Build the LDS image of the decoder parameters.
-std::vector<float> build_dec_image(const float* w) {
+std::vector<float> build_dec_image(const float* w, bool relu_scaled = false) {
     const WeightMap& m = wmap();
     std::vector<float> img(DEC_FLOATS, 0.f);
     auto put_layer = [&](int L, size_t woff, size_t boff) {
@@ -178,6 +179,13 @@ std::vector<float> build_dec_image(const float* w) {
             img[DEC_OFF_BIAS + (3 * (i - 1) + 2) * 32 + c] += img[DEC_OFF_BIAS + 3 * i * 32 + c];
             img[DEC_OFF_BIAS + 3 * i * 32 + c] = 0.f;
         }
+    }
+    if (relu_scaled && RELU_K != 0) {      // the layers fed by a ReLU (exact: a power of two; biases stay as they are)
+        const float sc = RELU_UP;
+        for (int i = 0; i < 5; ++i)
+            for (int j = 1; j <= 2; ++j)
+                for (int k = 0; k < W_LAYER; ++k) img[DEC_OFF_W + (3 * i + j) * W_LAYER + k] *= sc;
+        for (int c = 0; c < 32; ++c) img[DEC_OFF_WOUT + c] *= sc;
     }
     return img;
 }
@@ -363,6 +371,11 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     if (e == hipSuccess) {
         std::vector<float> img = build_dec_image(ctx->w.data());
         e = hipMemcpy(ctx->d_dec_img, img.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_dec_img_opt), DEC_FLOATS * sizeof(float));
+        if (e == hipSuccess) {
+            std::vector<float> img2 = build_dec_image(ctx->w.data(), true);
+            e = hipMemcpy(ctx->d_dec_img_opt, img2.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
+        }
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
@@ -398,6 +411,7 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     if (e != hipSuccess) {
         g_create_error = std::string("ifd_create: ") + hipGetErrorString(e);
         if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
+        if (ctx->d_dec_img_opt) (void)hipFree(ctx->d_dec_img_opt);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_w) (void)hipFree(ctx->d_w);
         if (ctx->d_unet) (void)hipFree(ctx->d_unet);
@@ -411,6 +425,7 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx);
     if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
+    if (ctx->d_dec_img_opt) (void)hipFree(ctx->d_dec_img_opt);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -556,7 +571,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
                                   static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
     }
-    e = launch_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
+    e = launch_optimize(ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
                         static_cast<const float*>(ctx->adam_tab), B, K, a, prm->split, ctx->n_cu, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
 }

@@ -40,6 +40,25 @@ constexpr int DEC_OFF_WOUT = DEC_OFF_WP + 32 * 4;    // [32]
 constexpr int DEC_OFF_BOUT = DEC_OFF_WOUT + 32;      // [1] (+3 pad)
 constexpr int DEC_FLOATS = DEC_OFF_BOUT + 4;         // 16964 floats = 67,856 B
 
+// ---- packed ReLU of the optimiser tile (optimize.hip decoder_tile3) ---------------------------------------------------
+// gfx950 has no packed f32 max, but VOP3P float instructions take the clamp modifier: v_pk_mul_f32 a, 2^-K clamp gives
+// relu(a) * 2^-K for TWO values in one instruction (for a < 2^K; the clamp's upper end), half the vector instructions of a
+// v_max per value.  The factor is undone for free: the optimiser kernel's copy of the parameter image holds fc_0 / fc_1 / fc_out
+// multiplied by 2^K (exact), so every product w * relu(a) has the same bits as before; in the backward pass the transposed
+// fc_1 / fc_0 products come out 2^K / 2^2K too large and the residual add that follows them (dn += mask * y) is a packed
+// fma with 2^-2K instead of a packed add - same instruction count, same rounding (one rounding of the same real number).
+// K = 40: activations must stay below 1.1e12 (they are O(1) ... O(1e3)), backward intermediates below 2^127 / 2^80 = 1.4e14.
+#ifndef IFD_RELU_K
+#define IFD_RELU_K 0                  // 0: one v_max per value, plain image (default); 40: the packed form (measured -0.3 %)
+#endif
+constexpr int RELU_K = IFD_RELU_K;
+// (only ever used to initialise the constexpr variables below: called with a run-time context the recursion would become
+// a real recursive device function - stack in scratch, s_swappc - which is what a first version of this did)
+__host__ __device__ constexpr float pow2i(int e) { return e == 0 ? 1.f : (e > 0 ? 2.f * pow2i(e - 1) : 0.5f * pow2i(e + 1)); }
+constexpr float RELU_UP = pow2i(RELU_K);            // 2^K:   factor on fc_0 / fc_1 / fc_out in the optimiser's image
+constexpr float RELU_DN = pow2i(-RELU_K);           // 2^-K:  the packed ReLU's multiplier
+constexpr float RELU_DN2 = pow2i(-2 * RELU_K);      // 2^-2K: undoes the two transposed products of a block in the backward pass
+
 constexpr int MAXK = 1024;           // points per cloud held in LDS (persistent optimiser kernel)
 constexpr int LARGE_MAXK = 10000;    // largest cloud of the launch-per-step path (optimize.hip, "large" section)
 constexpr int LARGE_LDS_MAXK = 4096; // ... up to here its repulsion accumulators sit in LDS, above in global memory

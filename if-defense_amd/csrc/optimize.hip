@@ -408,6 +408,65 @@ __device__ __forceinline__ Mask8 mask_alive_packed(const f32x8& v, const f32x8& 
     return m;
 }
 
+// relu(v) * 2^-RELU_K for the eight values of a sub-tile and layer: four v_pk_mul_f32 ... clamp (ifd_device.h "packed ReLU").
+// The instruction is inline asm (clang folds the clamp into scalar multiplies only), and the compiler pads MFMA -> VALU
+// read-after-write hazards for its own instructions, not for inline asm: each statement therefore takes the mask word of its
+// M-tile as an (unused) input - the v_perm that made that word is the compiler's own read of the same MFMA result quad.
+__device__ __forceinline__ f32x8 relu8s(const f32x8& v, const Mask8& m, unsigned long long sc2) {
+    f32x8 o;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#ifdef IFD_RELU_NOASM
+        o[2 * h] = fminf(fmaxf(v[2 * h] * RELU_DN, 0.f), 1.f);
+        o[2 * h + 1] = fminf(fmaxf(v[2 * h + 1] * RELU_DN, 0.f), 1.f);
+#else
+        const f32x2 in = {v[2 * h], v[2 * h + 1]};
+        f32x2 out;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] clamp" : "=v"(out) : "v"(in), "s"(sc2), "v"(m.w[h >> 1]));
+        o[2 * h] = out.x;
+        o[2 * h + 1] = out.y;
+#endif
+    }
+    return o;
+}
+// (the pair of relu and mask of one sub-tile and layer, either way)
+__device__ __forceinline__ void relu_and_mask(const f32x8& v, int c31, unsigned long long sc2, f32x8& r, Mask8& m) {
+    if (RELU_K != 0) {
+        m = mask_alive_packed(v, v, c31);
+        r = relu8s(v, m, sc2);
+    } else {
+        r = relu8(v);
+        m = mask_alive_packed(v, r, c31);
+    }
+}
+// d += t * 2^-2K (RELU_K != 0: the transposed fc_1 / fc_0 products carry 2^2K) or d += t: four packed instructions either way
+__device__ __forceinline__ void add8_scaled(f32x8& d, const f32x8& t) {
+    if (RELU_K == 0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x2 v = f32x2{d[2 * h], d[2 * h + 1]} + f32x2{t[2 * h], t[2 * h + 1]};
+            d[2 * h] = v.x; d[2 * h + 1] = v.y;
+        }
+    } else {
+        // (inline asm: left to itself the compiler turns the constant operand into eight scalar v_fma_f32; the inputs come from
+        // vector instructions - the mask application - so there is no MFMA hazard to pad here)
+        constexpr unsigned int cb = __builtin_bit_cast(unsigned int, RELU_DN2);
+        const unsigned long long c2 = ((unsigned long long)cb << 32) | cb;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+#ifdef IFD_RELU_NOASM
+            d[2 * h] = __builtin_fmaf(t[2 * h], RELU_DN2, d[2 * h]);
+            d[2 * h + 1] = __builtin_fmaf(t[2 * h + 1], RELU_DN2, d[2 * h + 1]);
+#else
+            f32x2 v = {d[2 * h], d[2 * h + 1]};
+            const f32x2 tt = {t[2 * h], t[2 * h + 1]};
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(v) : "v"(tt), "s"(c2));
+            d[2 * h] = v.x; d[2 * h + 1] = v.y;
+#endif
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The two-sub-tile schedule, software-pipelined (32 MFMAs per layer, 16 LDS reads - every A operand feeds both).
 //   region k.1 :  16 MFMAs of sub-tile 0, layer k   ||  VALU epilogue (bias/ReLU/mask) of sub-tile 1, layer k-1
@@ -718,6 +777,8 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     float bout = 0.f;
     int c31 = 31;                                  // shift count of the sign-byte extraction (an SDWA operand must be a register)
     asm volatile("" : "+v"(c31));
+    // 2^-RELU_K in both halves of an SGPR pair (the packed ReLU's second operand)
+    const unsigned long long sc2 = ((unsigned long long)__builtin_bit_cast(unsigned int, RELU_DN) << 32) | __builtin_bit_cast(unsigned int, RELU_DN);
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) {
         const float* Wl = Wd + 3 * i * W_LAYER;
@@ -730,15 +791,15 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         const Acc2 B0 = bias(3 * i + 1);
         mfma16(A, c[1], a1);
         const f32x8 af0 = flat(a0);
-        const f32x8 ra0 = relu8(af0);
-        mask_a[0][i] = mask_alive_packed(af0, ra0, c31);
+        f32x8 ra0;
+        relu_and_mask(af0, c31, sc2, ra0, mask_a[0][i]);
         region_end<TV, 1>();
         T2(5 + 6 * i + 1);
         Acc2 h0 = B0;                                                          // R3
         mfma16(A0, ra0, h0);
         const f32x8 af1 = flat(a1);
-        const f32x8 ra1 = relu8(af1);
-        mask_a[1][i] = mask_alive_packed(af1, ra1, c31);
+        f32x8 ra1;
+        relu_and_mask(af1, c31, sc2, ra1, mask_a[1][i]);
         region_end<TV, 0>();
         T2(5 + 6 * i + 2);
         const WFrag A1 = load_wfrag<false>(Wl + 2 * W_LAYER, lo);             // R4: prefetch fc_1
@@ -746,15 +807,15 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         Acc2 h1 = B0;
         mfma16(A0, ra1, h1);
         const f32x8 hf0 = flat(h0);
-        const f32x8 rh0 = relu8(hf0);
-        mask_h[0][i] = mask_alive_packed(hf0, rh0, c31);
+        f32x8 rh0;
+        relu_and_mask(hf0, c31, sc2, rh0, mask_h[0][i]);
         region_end<TV, 1>();
         T2(5 + 6 * i + 3);
         Acc2 o0 = acc_add(B1, a0);                                             // R5
         mfma16(A1, rh0, o0);
         const f32x8 hf1 = flat(h1);
-        const f32x8 rh1 = relu8(hf1);
-        mask_h[1][i] = mask_alive_packed(hf1, rh1, c31);
+        f32x8 rh1;
+        relu_and_mask(hf1, c31, sc2, rh1, mask_h[1][i]);
         region_end<TV, 0>();
         T2(5 + 6 * i + 4);
         if (i + 1 < NBLK) {                                                    // R6: prefetch next fc_c / first fc_1^T
@@ -781,8 +842,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const f32x8 nf = flat(net[t]);
-        const f32x8 rn = relu8(nf);
-        const Mask8 mask_n = mask_alive_packed(nf, rn, c31);
+        f32x8 rn;
+        Mask8 mask_n;
+        relu_and_mask(nf, c31, sc2, rn, mask_n);
         float part = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) part = fmaf(wout[r], rn[r], part);
@@ -807,8 +869,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         }
         {
             f32x8 dw;
+            const float dls = RELU_K != 0 ? dl * RELU_DN : dl;      // (fc_out sits in the image times 2^K: same products)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) dw[r] = dl * wout[r];
+            for (int r = 0; r < 8; ++r) dw[r] = dls * wout[r];
             dn[t] = masked(dw, mask_n);
         }
     }
@@ -841,14 +904,14 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
         mfma16(A0, dh1, y1);
         {
             const f32x8 t = masked(y0, mask_a[0][i]);
-            add8_pk(dn[0], t);                                                 // delta a_i
+            add8_scaled(dn[0], t);                                             // delta a_i
         }
         region_end<1, 1>();
         T2(36 + 6 * (NBLK - 1 - i) + 3);
         mfma16(Ac, dn[0], dcc[0]);                                             // R5: dc += fc_c^T da (sub-tile 0)
         {
             const f32x8 t = masked(y1, mask_a[1][i]);
-            add8_pk(dn[1], t);
+            add8_scaled(dn[1], t);
         }
         region_end<1, 0>();
         T2(36 + 6 * (NBLK - 1 - i) + 4);

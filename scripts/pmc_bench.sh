@@ -36,6 +36,14 @@ if a.get("SQ_WAVE_CYCLES"):
     a["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["SQ_WAVE_CYCLES"] * 4 / 2) if a.get("SQ_VALU_MFMA_BUSY_CYCLES") else None
     a["valu_non_mfma_per_simd_step"] = (a.get("SQ_INSTS_VALU", 0) - a.get("SQ_INSTS_MFMA", 0)) / (clouds * 4) / 501
     a["valu_to_mfma"] = (a.get("SQ_INSTS_VALU", 0) - a.get("SQ_INSTS_MFMA", 0)) / max(1.0, a.get("SQ_INSTS_MFMA", 0))
+    # pipe occupancy (round 4): f32 MFMA and the other vector instructions share one datapath on gfx950, so what the SIMDs can
+    # be asked for is MFMA-busy cycles + issue cycles of the non-MFMA vector instructions (a wave64 instruction occupies the
+    # 16-lane pipe for 4 cycles; packed / transcendental / DPP ones longer, so this is a lower bound) over SIMD cycles
+    simd = a["SQ_WAVE_CYCLES"] * 4 / 2
+    nv = a.get("SQ_INSTS_VALU", 0) - a.get("SQ_INSTS_MFMA", 0)
+    a["valu_issue_frac_at_4_cycles"] = 4.0 * nv / simd
+    a["pipe_occupancy_lower_bound"] = (a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) + 4.0 * nv) / simd
+    a["lds_issue_frac"] = a.get("SQ_ACTIVE_INST_LDS", 0) * 4 / simd if a.get("SQ_ACTIVE_INST_LDS") else None
 a["command"] = "bash scripts/pmc_bench.sh $TAG $CLOUDS: separate rocprofv3 --pmc passes over bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline --no-overlap (one optimize_kernel launch of $CLOUDS clouds x 501 steps on the bench workload)"
 json.dump(a, open("$R/gpurun_out/pmc_bench_$TAG.json", "w"), indent=1)
 print(json.dumps(a, indent=1))
