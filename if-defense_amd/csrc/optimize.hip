@@ -378,7 +378,17 @@ __device__ __forceinline__ void put_sign_byte(uint32_t& x, float v, float rv, in
 }
 __device__ __forceinline__ Mask8 mask_alive_packed(const f32x8& v, const f32x8& rv, int c31) {
     Mask8 m;
-#ifdef IFD_MASK_SDWA          // round 2: one SDWA sign-byte shift per value (+ one s_nop between partial writes of a word) and a v_not
+#ifdef IFD_EXACT_REP          // the exact-arithmetic build (libifd_exact.so): torch's rule, threshold_backward passes where v > 0 -
+                              // a pre-activation of exactly +0.0 is DEAD (the default build below keeps the sign bit: +0.0 alive)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t x = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x |= (v[4 * h + r] > 0.f ? 0xffu : 0u) << (8 * (3 - r));
+        asm volatile("" : "+v"(x));
+        m.w[h] = x;
+    }
+#elif defined(IFD_MASK_SDWA)          // round 2: one SDWA sign-byte shift per value (+ one s_nop between partial writes of a word) and a v_not
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         uint32_t x;                                  // byte 3 - r of word h: 0xff where value 4 h + r has its sign bit set
