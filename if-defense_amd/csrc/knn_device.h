@@ -559,6 +559,11 @@ __device__ __forceinline__ void rep_point(const f32x4* __restrict__ X, long long
 // graph in three dimensions is at most 5 x 12 (kissing number): |sum| <= 65 x 1.4 = 91 < 256, whatever the input
 // (test_repulsion_accumulators_do_not_wrap_on_a_tight_cluster holds the kernel against ifd_repulsion's 64-bit sums).  12 bytes of atomics per term instead of 24 (the phase is bound by LDS atomic throughput, not by arithmetic), 3
 // conversion instructions per component instead of 11, 12 KB of LDS instead of 24.
+__device__ __forceinline__ int opaque_zero_nomem() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
 struct RepAcc {
     long long* xy;       // [MAXK]
     int* z;              // [MAXK]
@@ -1058,8 +1063,14 @@ __device__ __forceinline__ void adam_phase(f32x4* __restrict__ X, const f32x4* _
                 fi[2] += __hip_atomic_exchange(cv.ws->Fz + pt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             unpack_xy(fxy, fi[0], fi[1]);
-            F.xy[pt] = 0;
-            F.z[pt] = 0;
+            {   // clear the accumulators with a zero made HERE: the literal 0 of a 64-bit store is a register pair the compiler hoists
+                // out of the step loop and spills across the decoder tiles - its reload was a scratch round trip per point
+                const int z0 = opaque_zero_nomem();
+                int* fw = reinterpret_cast<int*>(F.xy + pt);
+                fw[0] = z0;
+                fw[1] = z0;
+                F.z[pt] = z0;
+            }
             rep_overflow_check(fi, status);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {

@@ -784,7 +784,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
     // ---- forward MLP, software pipelined ---------------------------------------------------------------------
     Mask8 mask_a[2][NBLK], mask_h[2][NBLK];
     f32x8 wout;
-    float bout = 0.f;
+    float bout = 0.f, ilb = 0.f;
     int c31 = 31;                                  // shift count of the sign-byte extraction (an SDWA operand must be a register)
     asm volatile("" : "+v"(c31));
     // 2^-RELU_K in both halves of an SGPR pair (the packed ReLU's second operand)
@@ -838,7 +838,9 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
             const f32x4 t1 = *reinterpret_cast<const f32x4*>(W + DEC_OFF_WOUT + 16 + lo.q4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
-            bout = W[DEC_OFF_BOUT];
+            const f32x2 bo = *reinterpret_cast<const f32x2*>(W + DEC_OFF_BOUT);        // {fc_out's bias, 1 / B of the cloud (optimize_kernel)}
+            bout = bo.x;
+            ilb = bo.y;
         }
         Acc2 o1 = acc_add(B1, a1);
         mfma16(A1, rh1, o1);
@@ -871,7 +873,7 @@ __device__ __forceinline__ void decoder_tile3(const float* __restrict__ W, __amd
 #endif
             const float rc = __builtin_amdgcn_rcpf(1.f + e);
             const float sig = logit >= 0.f ? rc : e * rc;
-            dl = (sig - thr) * inv_lb;
+            dl = (sig - thr) * ilb;
             bce[t] = want_loss ? fmaxf(logit, 0.f) - thr * logit + log1pf(e) : 0.f;
         } else {
             bce[t] = logit;
@@ -1082,8 +1084,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     constexpr int NT = 32 / S, NTH = 16 / S;        // 32-point decoder tiles of this workgroup: NTH in each half of the cloud
     auto tile_base = [&](int t) { return (t / NTH) * OPT_THREADS + member * (PTS / 2) + (t % NTH) * 32; };
 
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);          // scalar: survives the tile phase for free
+    auto hw_tid = [&]() __attribute__((always_inline)) {
+        unsigned int ones;                                   // (volatile: the mbcnt pair is otherwise loop-invariant - hoisted and spilled)
+        asm volatile("s_mov_b32 %0, -1" : "=s"(ones));
+        int t = wave_u * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        asm volatile("" : "+v"(t));
+        return t;
+    };
     const unsigned long long t_begin = __builtin_readcyclecounter();     // shader clock (s_memtime)
     load_dec_image(W, dec_img);
+    __syncthreads();                                     // (the image's padding words are written: one of them is re-used below)
     // Per-thread state of the kNN / Adam phases: the neighbour-list certificates are parked in scratch while the decoder
     // tiles run (knn_device.h "Parking"), the Adam moments in LDS (MV) - the tile phase owns the whole register file.
     f32x4 park[PARK_SLOTS];
@@ -1113,7 +1124,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             for (int i = tid; i < K; i += NW * 64) X[i] = f32x4{pc[3 * i], pc[3 * i + 1], pc[3 * i + 2], 1.f};
         park_knnpt(park, z, PARK_KNN, k0);
         park_knnpt(park, z, PARK_KNN + 4, k0);
-        park[z + PARK_KNN + 3] = f32x4{0.f, 0.f, 0.f, 0.f};          // rep_loss_a / rep_loss_b of the last step
     }
     for (int i = tid; i < MAXK; i += NW * 64) { F.xy[i] = 0; F.z[i] = 0; }
     if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 1.f};
@@ -1123,7 +1133,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
     const int loss_batch = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : A.loss_batch;
     const float inv_lb = 1.0f / (float)loss_batch;
-    const float rep_scale = A.rep_weight / ((float)loss_batch * (float)K * 5.f);
+    // The decoder tiles take 1 / B from a spare word of the parameter image in LDS, next to fc_out's bias (one ds_read_b64 for
+    // both): as a kernel-lifetime register value it was spilled across the 256-register tiles and reloaded from scratch at the
+    // forward -> backward turn-around of EVERY tile, in front of the loss derivative the whole backward pass waits for.
+    if (tid == 0) W[DEC_OFF_BOUT + 1] = inv_lb;
+    // (uniform: kept in a scalar register - as a vector value the compiler broadcast it into a register PAIR for the packed fma of
+    // the Adam phase, kept the pair alive across the whole step loop and spilled it: a scratch round trip in the middle of every
+    // Adam phase, `profiles/r04_*`)
+    const float rep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(A.rep_weight / ((float)loss_batch * (float)K * 5.f))));
     const bool use_rep = A.rep_weight > 0.f;
     uint16_t* cloud_lists = knn_lists + (size_t)cloud * MAXK * LIST_M;   // certified neighbour lists, global (L2-resident)
     float* dmaxbuf = scratch + 32;                                   // [2][MAX_WAVES] per-wave max |x - x0| (next step)
@@ -1161,11 +1178,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         // Everything a phase derives from the thread index (LDS addresses of candidates, list pointers, tile lanes) is
         // re-derived from an opaque copy once per step: left alone, LICM hoists those cheap invariants out of the
         // 501-step loop and they end up in scratch, reloaded one by one inside the phases.
-        int tid_s = tid;
-        asm volatile("" : "+v"(tid_s));
-        const int lane = tid_s & 63, wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
-        const bool owner = tid_s < OT;
-        const int pa = owner ? point_a(tid_s) : MAXK, pb = (S == 1 && owner) ? tid_s + OPT_THREADS : MAXK;
+        // (Round 4: the copy is made from hardware state - the wave's index sits in a scalar register, the lane index is two
+        // mbcnt instructions - and made AGAIN behind the tile phase: a value derived from threadIdx before the tiles and used in
+        // the Adam phase is live across 256-register tiles, i.e. spilled, and its reload was a scratch round trip right behind the
+        // mid-step barrier, on every wave's critical path.)
+        int tid_s = hw_tid();
+        int lane = tid_s & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid_s >> 6);
+        bool owner = tid_s < OT;
+        int pa = owner ? point_a(tid_s) : MAXK, pb = (S == 1 && owner) ? tid_s + OPT_THREADS : MAXK;
         const CoopView cv = {cws, member, (step + 1) & 1};              // this step publishes into the buffers of parity (step + 1) & 1
         const bool arrives = S == 1 || member != A.test_drop_member;    // (test hook: a member that never arrives, coop_wait's bound)
 #if defined(IFD_PROF)
@@ -1250,7 +1271,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             const int z2 = opaque_zero();
             park_knnpt(park, z2, PARK_KNN, ka);
             park_knnpt(park, z2, PARK_KNN + 4, kb);
-            if (want_loss) park[z2 + PARK_KNN + 3] = f32x4{rep_loss_a, rep_loss_b, 0.f, 0.f};
+            if (want_loss) {       // the last step's repulsion terms wait in the unused fourth word of the points' sampling coordinates
+                if (pa < K) reinterpret_cast<float*>(PIX + pa)[3] = rep_loss_a;
+                if (pb < K) reinterpret_cast<float*>(PIX + pb)[3] = rep_loss_b;
+            }
             if (S > 1) {       // the member's last owner wave sends what its points owe to points of the other members
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wave's LDS atomics are done
                 int done = 0;
@@ -1267,13 +1291,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
         PROF_ACC(pc_tiles);
 // [pcsamp:step.adam]
         // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------
+        tid_s = hw_tid();                                        // nothing thread-derived crosses the tile phase (see the step's head)
+        lane = tid_s & 63;
+        owner = tid_s < OT;
+        pa = owner ? point_a(tid_s) : MAXK;
+        pb = (S == 1 && owner) ? tid_s + OPT_THREADS : MAXK;
         AdamState ast;
         KnnPt ka, kb;
-        const int z3 = opaque_zero();
         load_adam(MV, min(tid_s, OPT_THREADS - 1), ast);
+        const int z3 = opaque_zero();
         unpark_knnpt(park, z3, PARK_KNN, ka);
         unpark_knnpt(park, z3, PARK_KNN + 4, kb);
-        const f32x4 rl = park[z3 + PARK_KNN + 3];
+        // (Rounds 2-3 parked the last step's repulsion terms in scratch next to the certificates and read the slot back here on
+        // every step: two of its four words were never used, the register allocator re-used them while the load was in flight,
+        // and the write-after-write wait it had to insert drained ALL the parked state in front of the mid-step barrier - on
+        // every wave, every step.  They live in PIX[].w now - LDS, written and read on the last step only.)
+        f32x2 rl = {0.f, 0.f};
+        if (want_loss) rl = f32x2{pa < K ? PIX[pa].w : 0.f, pb < K ? PIX[pb].w : 0.f};
         const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
         // split clouds: every owner wave of the cloud has sent its neighbour terms (the wait rode under the decoder tiles)
         if (S > 1 && use_rep && wave == 0 &&
