@@ -225,6 +225,7 @@ hipError_t ensure_ws(ifd_ctx* ctx, size_t bytes) { return ensure_buf(&ctx->ws, &
 struct UNetPack {
     std::vector<float> data;
     size_t down_w[4][2], down_b[4][2], up_t_w[3], up_t_b[3], up_w[3][2], up_b[3][2], fin_w, fin_b;
+    size_t down_u[4][2], up_u[3][2];         // Winograd-domain copies of the 3x3 layers
 };
 UNetPack pack_unet(const float* w) {
     const WeightMap& m = wmap();
@@ -235,6 +236,26 @@ UNetPack pack_unet(const float* w) {
         for (int o = 0; o < co; ++o)
             for (int i = 0; i < ci; ++i)
                 for (int t = 0; t < k * k; ++t) P.data[at + ((size_t)t * ci + i) * co + o] = w[src + ((size_t)o * ci + i) * k * k + t];
+        return at;
+    };
+    // Winograd F(2x2, 3x3) filter transform U = G g G^T (G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]]), in
+    // double, rounded once; layout [Cin / 16][xi = 4 i + j][Cout][16]: the slab of one 16-channel chunk and a range of output
+    // channels is 16 contiguous pieces, and a lane's four k-steps of one MFMA group are 16 contiguous bytes (unet.hip)
+    auto wino = [&](size_t src, int co, int ci) {
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        size_t at = P.data.size();
+        P.data.resize(at + (size_t)16 * ci * co);
+        for (int o = 0; o < co; ++o)
+            for (int i = 0; i < ci; ++i) {
+                const float* g = w + src + ((size_t)o * ci + i) * 9;
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        double u = 0.0;
+                        for (int y = 0; y < 3; ++y)
+                            for (int x = 0; x < 3; ++x) u += G[a][y] * (double)g[3 * y + x] * G[b][x];
+                        P.data[at + ((((size_t)(i / 16) * 16 + (4 * a + b)) * co + o) * 16) + i % 16] = (float)u;
+                    }
+            }
         return at;
     };
     auto convt = [&](size_t src, int ci, int co) {
@@ -255,6 +276,8 @@ UNetPack pack_unet(const float* w) {
     for (int i = 0; i < 4; ++i) {
         P.down_w[i][0] = conv(m.down_w[i][0], ch[i], cin, 3); P.down_b[i][0] = vec(m.down_b[i][0], ch[i]);
         P.down_w[i][1] = conv(m.down_w[i][1], ch[i], ch[i], 3); P.down_b[i][1] = vec(m.down_b[i][1], ch[i]);
+        P.down_u[i][0] = wino(m.down_w[i][0], ch[i], cin);
+        P.down_u[i][1] = wino(m.down_w[i][1], ch[i], ch[i]);
         cin = ch[i];
     }
     for (int i = 0; i < 3; ++i) {
@@ -262,6 +285,8 @@ UNetPack pack_unet(const float* w) {
         P.up_t_w[i] = convt(m.up_t_w[i], cin, co); P.up_t_b[i] = vec(m.up_t_b[i], co);
         P.up_w[i][0] = conv(m.up_w[i][0], co, 2 * co, 3); P.up_b[i][0] = vec(m.up_b[i][0], co);
         P.up_w[i][1] = conv(m.up_w[i][1], co, co, 3); P.up_b[i][1] = vec(m.up_b[i][1], co);
+        P.up_u[i][0] = wino(m.up_w[i][0], co, 2 * co);
+        P.up_u[i][1] = wino(m.up_w[i][1], co, co);
         cin = co;
     }
     P.fin_w = conv(m.fin_w, 32, 32, 1); P.fin_b = vec(m.fin_b, 32);
@@ -398,14 +423,15 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         const float* d = ctx->d_unet;
         UNetWeights& u = ctx->uw;
         for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 2; ++j) { u.down_w[i][j] = d + P.down_w[i][j]; u.down_b[i][j] = d + P.down_b[i][j]; }
+            for (int j = 0; j < 2; ++j) { u.down_w[i][j] = d + P.down_w[i][j]; u.down_b[i][j] = d + P.down_b[i][j]; u.down_u[i][j] = d + P.down_u[i][j]; }
         for (int i = 0; i < 3; ++i) {
             u.up_t_w[i] = d + P.up_t_w[i]; u.up_t_b[i] = d + P.up_t_b[i];
-            for (int j = 0; j < 2; ++j) { u.up_w[i][j] = d + P.up_w[i][j]; u.up_b[i][j] = d + P.up_b[i][j]; }
+            for (int j = 0; j < 2; ++j) { u.up_w[i][j] = d + P.up_w[i][j]; u.up_b[i][j] = d + P.up_b[i][j]; u.up_u[i][j] = d + P.up_u[i][j]; }
         }
         u.fin_w = d + P.fin_w; u.fin_b = d + P.fin_b;
     }
     if (e == hipSuccess) e = configure_encoder_kernels();
+    if (e == hipSuccess) e = configure_unet_kernels();
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e != hipSuccess) {

@@ -38,7 +38,10 @@ struct UNetWeights {
     const float *down_w[4][2], *down_b[4][2];
     const float *up_t_w[3], *up_t_b[3], *up_w[3][2], *up_b[3][2];
     const float *fin_w, *fin_b;
+    // the 3x3 layers once more in the Winograd F(2x2, 3x3) domain: U = G g G^T, [Cin / 16][16 xi][Cout][16] (unet.hip wino_kernel)
+    const float *down_u[4][2], *up_u[3][2];
 };
+hipError_t configure_unet_kernels();
 size_t unet_workspace_floats(int n_img);
 hipError_t launch_unet(const UNetWeights& W, const float* x, float* out, float* ws, int n_img, hipStream_t s);
 

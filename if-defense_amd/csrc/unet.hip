@@ -14,6 +14,8 @@
 //             ConvTranspose2d(k=2, s=2) as four 1x1 convolutions with a strided store.
 // Results are independent of the batch size (fixed summation order) - unlike a library convolution whose
 // algorithm choice depends on it - which the bitwise sharding-invariance of the whole path relies on.
+#include <cstdio>
+#include <type_traits>
 #include "ifd_device.h"
 #include "ifd_internal.h"
 
@@ -227,11 +229,376 @@ static hipError_t launch_conv(const ConvArgs& a, int n_img, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 convolutions in the Winograd F(2x2, 3x3) domain (round 4): 16 multiplications per 2x2 output tile and channel pair
+// instead of 36 - 2.25x fewer MFMA cycles than the implicit GEMM above, for two cheap transforms:
+//   V = B^T d B   per 4x4 input patch and input channel   (32 additions; fused into the LDS staging),
+//   M_xi = V_xi U_xi, xi = 0 .. 15: sixteen independent [tiles x Cin] . [Cin x Cout] products on v_mfma_f32_16x16x4_f32,
+//   Y = A^T M A   per tile and output channel             (24 additions; in registers).
+// U = G g G^T is computed on the host in double (api.cpp pack_unet).  F(2x2, 3x3) has the transform matrices of 0, +-1, 1/2
+// only: measured against a float64 convolution its error is ~2x the direct float32 sum's (4e-7 against 2e-7 of the output's
+// maximum at Cin = 128 - scripts/wino_error.py), two orders below the tolerance the planes are held to.
+//
+//   block    4 waves = TG tile groups x CG channel groups; a tile group is 16 Winograd tiles = 4 x 4 tiles = 8 x 8 output
+//            pixels (groups side by side), a channel group 16 output channels.  Wave (tg, cg) keeps ALL 16 xi accumulators
+//            of its 16 tiles x 16 channels (64 VGPRs): the D layout puts the 16 xi of a (tile, channel) pair into one lane,
+//            so the output transform, bias, ReLU and the fused 2x2 max-pool (a Winograd tile IS a pooling cell) need no
+//            exchange.
+//   staging  per chunk of 16 input channels: every thread transforms its share of the patches (tile, 4 channels, TG of the
+//            4 xi rows) from registers (loaded one chunk ahead) and writes V as 16-byte pieces [xi][tile][16 ch]; the weight
+//            slab [xi][cout][16 ch] is copied as it lies in memory.
+//   operands one ds_read_b128 per operand and xi feeds FOUR MFMAs (k-slot (s, kq) <-> channel 4 kq + s on both sides); the
+//            16-byte pieces of a row are XOR-swizzled by its index so that the b128 lane groups are conflict-free at a row
+//            of 64 bytes (no padding: 64 KB of LDS per block at TG = CG = 2, two blocks per CU).
+// Fixed summation order, independent of the batch: the bitwise sharding invariance of the path holds as before.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wswz(int r) { return (r >> 2) & 2; }        // piece kq of row r sits at kq ^ wswz(r & 15)
+
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wino_rsrc(const float* p, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int TG, int CG>
+__global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kernel(ConvArgs a, int items_per_block, int n_items) {
+    static_assert((TG == 1 || TG == 2) && (CG == 2 || CG == 4), "4 or 8 waves");
+    constexpr int NT = 16 * TG, NCO = 16 * CG, NTHR = 64 * TG * CG;
+    constexpr int RPT = 4 / CG;                  // xi rows per thread in the input transform: NT * 4 * (4 / RPT) = NTHR threads
+    constexpr int NROW = RPT + 1;                // patch rows a thread needs for them
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* s_v = wsm;                            // [16 xi][NT tiles][16 ch]
+    float* s_u = wsm + 16 * NT * 16;             // [16 xi][NCO couts][16 ch]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tg = wave % TG, cg = wave / TG;
+    const int regions_x = a.W / (8 * TG), regions = regions_x * (a.H / 8);
+    const int co0 = (int)blockIdx.y * NCO;
+    const int Cin = a.C0 + a.C1, n_chunks = Cin / 16;
+    // A block walks `items_per_block` work items (image, region) and their chunks of 16 input channels as ONE sequence of steps,
+    // the global loads of step k + 1 in flight under the MFMAs of step k: the memory latency is paid once per block, not once
+    // per region (a 64^2 layer with 32 input channels has two chunks per region).
+    const int item0 = (int)blockIdx.x * items_per_block;
+    const int n_my = min(items_per_block, n_items - item0);
+    const int n_steps = n_my * n_chunks;
+
+    // ---- the thread's share of the input transform: tile ut, channel piece ucq, xi rows [RPT uh, RPT uh + RPT) ----
+    // (uh is wave-uniform: 4 NT threads per value)
+    const int ucq = tid & 3, ut = (tid >> 2) % NT;
+    const int uh = __builtin_amdgcn_readfirstlane(tid / (4 * NT));
+    const int utt = ut & 15, uty = utt >> 2, utx = utt & 3;
+    const int pyo = 2 * uty - 1, pxo = 8 * (ut >> 4) + 2 * utx - 1;       // top-left of the 4x4 patch inside the region
+    // patch rows: RPT 2: uh .. uh + 2; RPT 1: {0 | 1, 2 | 3}
+    // Loads are buffer loads (the image is the buffer, 32-bit byte offsets, out-of-image taps get an offset beyond the buffer
+    // and come back as the zero padding): no 64-bit address arithmetic, no branches around the loads.
+    const int cs = a.C0;                                                   // (both sources of a concat layer have C0 channels: conv())
+    const unsigned int img_bytes = (unsigned int)(a.H * a.W * cs) * 4u;
+    int yrel[NROW], xrel[4], poff[NROW][4];
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) yrel[k] = pyo + (RPT == 2 ? uh + k : (k == 0 ? (uh == 0 ? 0 : 1) : (uh == 3 ? 3 : 2)));
+#pragma unroll
+    for (int x = 0; x < 4; ++x) xrel[x] = pxo + x;
+#pragma unroll
+    for (int k = 0; k < NROW; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) poff[k][x] = ((yrel[k] * a.W + xrel[x]) * cs + 4 * ucq) * 4;
+    constexpr int W_IT = (16 * NCO * 4) / NTHR;  // f32x4 pieces of the weight slab per thread
+    int woff[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int i = tid + it * NTHR;
+        const int cq = i & 3, nn = (i >> 2) % NCO, xi = i / (4 * NCO);
+        woff[it] = ((xi * a.Cout + co0 + nn) * 16 + 4 * cq) * 4;
+    }
+    const __amdgpu_buffer_rsrc_t wrs = wino_rsrc(a.w, (unsigned int)(16 * Cin * a.Cout) * 4u);
+    f32x4 rin[NROW][4], rw[W_IT];
+    // (image, region row, region column, chunk) of the step being fetched, advanced by one step per call - no divisions by run-time
+    // values inside the loop (each is ~25 dependent instructions in front of the loads, and the MFMAs queue up behind them)
+    int f_n = item0 / regions, f_ry = ((item0 % regions) / regions_x) * 8, f_rx = ((item0 % regions) % regions_x) * 8 * TG, f_c0 = 0;
+    auto fetch = [&](bool live) {                  // live = false: nothing left to fetch - every tap out of range (the loads return 0)
+        const int n = live ? f_n : 0, ry = f_ry, rx = f_rx, c0 = f_c0;
+        f_c0 += 16;
+        if (f_c0 == Cin) {
+            f_c0 = 0;
+            f_rx += 8 * TG;
+            if (f_rx == a.W) {
+                f_rx = 0;
+                f_ry += 8;
+                if (f_ry == a.H) { f_ry = 0; ++f_n; }
+            }
+        }
+        const float* src = (c0 < a.C0 ? a.in0 : a.in1) + (size_t)n * a.H * a.W * cs;
+        const __amdgpu_buffer_rsrc_t irs = wino_rsrc(src, img_bytes);
+        const int base = ((ry * a.W + rx) * cs + (c0 < a.C0 ? c0 : c0 - a.C0)) * 4;      // (uniform)
+        bool vx[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) vx[x] = (unsigned int)(rx + xrel[x]) < (unsigned int)a.W;
+#pragma unroll
+        for (int k = 0; k < NROW; ++k) {
+            const bool vy = live && (unsigned int)(ry + yrel[k]) < (unsigned int)a.H;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int off = (vy && vx[x]) ? base + poff[k][x] : (int)0x80000000;
+                rin[k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, off, 0, 0));
+            }
+        }
+        const int wbase = (c0 / 16) * 16 * a.Cout * 16 * 4;                              // [xi][Cout][16] of this chunk
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it)
+            rw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[it], wbase, 0));
+    };
+    // B^T d B for the thread's xi rows: row combination first, then the columns; one 16-byte store per xi
+    float* const vdst = s_v + ut * 16 + 4 * (ucq ^ wswz(utt));
+    auto put_row = [&](int xr, const f32x4 (&R)[4]) {
+        const f32x4 v0 = R[0] - R[2], v1 = R[1] + R[2], v2 = R[2] - R[1], v3 = R[1] - R[3];
+        float* d = vdst + (size_t)(4 * xr) * NT * 16;
+        *reinterpret_cast<f32x4*>(d) = v0;
+        *reinterpret_cast<f32x4*>(d + NT * 16) = v1;
+        *reinterpret_cast<f32x4*>(d + 2 * NT * 16) = v2;
+        *reinterpret_cast<f32x4*>(d + 3 * NT * 16) = v3;
+    };
+    int udst[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int i = tid + it * NTHR;
+        const int cq = i & 3, nn = (i >> 2) % NCO, xi = i / (4 * NCO);
+        udst[it] = (xi * NCO + nn) * 16 + 4 * (cq ^ wswz(nn & 15));
+    }
+    auto transform = [&]() {
+        f32x4 R[4];
+        if (RPT == 2) {                            // uh 0: xi rows 0, 1 from patch rows 0 1 2; uh 1: xi rows 2, 3 from patch rows 1 2 3
+            if (uh == 0) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[0][x] - rin[2][x];
+                put_row(0, R);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[1][x] + rin[2][x];
+                put_row(1, R);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[1][x] - rin[0][x];
+                put_row(2, R);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[0][x] - rin[2][x];
+                put_row(3, R);
+            }
+        } else {                                   // one xi row per thread: patch rows {0, 2}, {1, 2}, {1, 2}, {1, 3}
+            if (uh == 1) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[0][x] + rin[1][x];
+            } else if (uh == 2) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[1][x] - rin[0][x];
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) R[x] = rin[0][x] - rin[1][x];
+            }
+            put_row(uh, R);
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) *reinterpret_cast<f32x4*>(s_u + udst[it]) = rw[it];
+    };
+
+    f32x4 acc[16];
+    const int r = lane & 15, kq = lane >> 4;
+    const float* ap = s_v + (tg * 16 + r) * 16 + 4 * (kq ^ wswz(r));
+    const float* bp = s_u + (cg * 16 + r) * 16 + 4 * (kq ^ wswz(r));
+    const int co = co0 + cg * 16 + r;
+    const float bias = a.bias[co];
+    const int st_lane = ((2 * kq * a.W + 8 * tg) * a.Cout + co) * 4;               // byte offset of the lane's first output pixel in its region
+    const int pl_lane = ((kq * (a.W / 2) + 4 * tg) * a.Cout + co) * 4;             // ... of its first pooled pixel
+    const unsigned int out_bytes = (unsigned int)(a.H * a.W * a.Cout) * 4u;
+
+#ifdef IFD_WINO_PROF
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
+#define WP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); pt[i] += t_ - tl; tl = t_; } while (0)
+#else
+#define WP(i)
+#endif
+    const bool slot_odd = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0;       // HW_ID.WAVE_ID bit 0: the wave slot on this SIMD
+    int e_n = f_n, e_ry = f_ry, e_rx = f_rx;       // the item whose chunks are being accumulated: the block's first
+    fetch(n_steps > 0);
+    int chunk = 0;
+#pragma unroll 1
+    for (int step = 0; step < n_steps; ++step) {
+        WP(5);
+        __syncthreads();                                                   // the previous step's MFMAs have read the LDS tiles
+        WP(0);
+#ifdef IFD_WINO_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WP(1);
+#endif
+        transform();
+        WP(2);
+        __syncthreads();
+        WP(3);
+        // 16 xi x 4 k-steps; the operands of xi pair p + 1 are requested before the MFMAs of pair p (two accumulator chains
+        // alternate: a dependent 16x16x4 MFMA every other issue).  The first chunk of an item starts its chains from the
+        // instruction's zero C operand instead of cleared registers (64 v_mov per item and wave).
+        // The global loads of the NEXT step are issued between the MFMAs, two or three per eight: in front of them, as one burst,
+        // the 20 x 1 KB requests of the four waves that leave the barrier together queue at the CU's one texture addresser for
+        // ~1.3 k cycles, and the in-order wave does not reach its first MFMA before its last load has issued (-DIFD_WINO_PROF:
+        // 3.7 k cycles for the 2 k of MFMAs even with the SIMD to itself).
+        auto mfma_chunk = [&](auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            fetch(step + 1 < n_steps);
+            f32x4 av[2][2], bv[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                av[0][e] = *reinterpret_cast<const f32x4*>(ap + e * NT * 16);
+                bv[0][e] = *reinterpret_cast<const f32x4*>(bp + e * NCO * 16);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int cur = p & 1, nxt = cur ^ 1;
+                if (p + 1 < 8) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        av[nxt][e] = *reinterpret_cast<const f32x4*>(ap + (2 * p + 2 + e) * NT * 16);
+                        bv[nxt][e] = *reinterpret_cast<const f32x4*>(bp + (2 * p + 2 + e) * NCO * 16);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x4 c = (FIRST && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[2 * p + e];
+                        acc[2 * p + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][e][s], bv[cur][e][s], c, 0, 0, 0);
+                    }
+                // the next pair's four LDS reads first, then this pair's eight MFMAs: every read has 256 matrix cycles to land
+                constexpr int NLD = NROW * 4 + W_IT;                      // global loads of a fetch, spread over the eight pairs
+                constexpr int LD_LO = NLD / 8, LD_HI = NLD / 4 - LD_LO;   // 4 LD_HI + 4 LD_LO = NLD
+                if (p == 0) __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);      // (the loads' address arithmetic)
+                if (p % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, LD_HI, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x020, LD_LO, 0);
+                if (p + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+        };
+        // Wave priority while the wave streams MFMAs - and a DIFFERENT one for the two waves that share a SIMD (two blocks per
+        // CU; the wave slot's low bit): measured per phase (-DIFD_WINO_PROF), the two blocks of a CU otherwise fall into step -
+        // both in their MFMA phases, interleaving (4.9 k cycles for 2 k of MFMAs), then both in their transform / barrier
+        // phases with the matrix pipe idle.  With the priorities one wave takes the pipe, finishes first and leaves for its
+        // transform while the other streams: the blocks alternate.
+#ifndef IFD_WINO_NOPRIO
+        if (slot_odd) asm volatile("s_setprio 3"); else asm volatile("s_setprio 2");
+#endif
+        if (chunk == 0) mfma_chunk(std::true_type{}); else mfma_chunk(std::false_type{});
+#ifndef IFD_WINO_NOPRIO
+        asm volatile("s_setprio 0");
+#endif
+        WP(4);
+        if (++chunk != n_chunks) continue;
+        chunk = 0;
+        // ---- Y = A^T M A, bias, ReLU, stores: lane = output channel co, kq = tile row, register = tile column ---------
+        const int n = e_n, y0 = e_ry, x0 = e_rx;
+        e_rx += 8 * TG;
+        if (e_rx == a.W) {
+            e_rx = 0;
+            e_ry += 8;
+            if (e_ry == a.H) { e_ry = 0; ++e_n; }
+        }
+        const __amdgpu_buffer_rsrc_t ors = wino_rsrc(a.out + (size_t)n * a.H * a.W * a.Cout, out_bytes);
+        const __amdgpu_buffer_rsrc_t prs = wino_rsrc(a.pool_out != nullptr ? a.pool_out + (size_t)n * (a.H / 2) * (a.W / 2) * a.Cout : a.out, out_bytes / 4u);
+        const int st_reg = (y0 * a.W + x0) * a.Cout * 4, pl_reg = ((y0 / 2) * (a.W / 2) + x0 / 2) * a.Cout * 4;
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = acc[j][tx] + acc[4 + j][tx] + acc[8 + j][tx];
+                t1[j] = acc[4 + j][tx] - acc[8 + j][tx] - acc[12 + j][tx];
+            }
+            float y[2][2];
+            y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t0[1] - t0[2] - t0[3];
+            y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
+#pragma unroll
+            for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+                for (int xb = 0; xb < 2; ++xb) {
+                    float v = y[ya][xb] + bias;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    y[ya][xb] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, st_lane, st_reg + ((ya * a.W + 2 * tx + xb) * a.Cout) * 4, 0);
+                }
+            if (a.pool_out != nullptr)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]))), prs,
+                                                      pl_lane, pl_reg + tx * a.Cout * 4, 0);
+        }
+    }
+#ifdef IFD_WINO_PROF
+    if (lane == 0 && a.fuse_b != nullptr) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.fuse_b));
+        for (int i = 0; i < 6; ++i) atomicAdd(o + i, pt[i]);
+        atomicAdd(o + 6, (unsigned long long)n_steps);
+    }
+#endif
+}
+
+#ifndef IFD_WINO_ITEMS
+#define IFD_WINO_ITEMS 16             // (image, region) work items per block
+#endif
+template <int TG, int CG>
+static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
+#ifdef IFD_WINO_OCC1
+    constexpr size_t LDS = 96 * 1024;
+#else
+    constexpr size_t LDS = (size_t)16 * 16 * (16 * TG + 16 * CG) * sizeof(float);
+#endif
+    const int n_items = n_img * (a.H / 8) * (a.W / (8 * TG));
+    // up to IFD_WINO_ITEMS items per block, fewer where that would leave less than ~12 blocks per block slot of the chip
+    const int gy = a.Cout / (16 * CG);
+    const int per = max(1, min(IFD_WINO_ITEMS, (int)((long long)n_items * gy / 6144)));
+    const dim3 grid((n_items + per - 1) / per, gy, 1);
+#ifdef IFD_WINO_PROF
+    static unsigned long long* dbg = nullptr;
+    if (dbg == nullptr) (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64);
+    (void)hipMemsetAsync(dbg, 0, 64, s);
+    ConvArgs b = a;
+    b.fuse_b = reinterpret_cast<const float*>(dbg);
+    hipLaunchKernelGGL((wino_kernel<TG, CG>), grid, dim3(64 * TG * CG), LDS, s, b, per, n_items);
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, dbg, 56, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    const double ws = (double)h[6];     // wave-steps
+    fprintf(stderr, "wino<%d,%d> HW %d Cin %d Cout %d: per wave-step cycles: barrier1 %.0f | vmcnt %.0f | transform %.0f | barrier2 %.0f | fetch+mfma %.0f | tail(epilogue,loop) %.0f\n",
+            TG, CG, a.H, a.C0 + a.C1, a.Cout, h[0] / ws, h[1] / ws, h[2] / ws, h[3] / ws, h[4] / ws, h[5] / ws);
+    return hipGetLastError();
+#else
+    hipLaunchKernelGGL((wino_kernel<TG, CG>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
+    return hipGetLastError();
+#endif
+}
+
+hipError_t configure_unet_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * 96 * 4);
+}
+
+// -DIFD_UNET_DIRECT / env IFD_UNET_DIRECT=1: every 3x3 layer on the implicit-GEMM kernel (A/B and validation of the Winograd path)
+static bool unet_direct() {
+#ifdef IFD_UNET_DIRECT
+    return true;
+#else
+    static const bool d = [] { const char* e = getenv("IFD_UNET_DIRECT"); return e != nullptr && e[0] == '1'; }();
+    return d;
+#endif
+}
+
 // conv3x3 / conv1x1 / transpose-conv dispatch on the image size (64/32/16 -> 8x16 pixel tiles, 8 -> 8x8 tiles)
 static hipError_t conv(const float* in0, int C0, const float* in1, int C1, const float* w, const float* b, float* out,
                        float* pool_out, int HW, int Cout, int ks, bool up, bool relu, int n_img, hipStream_t s,
-                       const float* fuse_w = nullptr, const float* fuse_b = nullptr) {
+                       const float* fuse_w = nullptr, const float* fuse_b = nullptr, const float* wu = nullptr) {
     ConvArgs a{in0, in1, w, b, out, pool_out, HW, HW, C0, C1, Cout, relu ? 1 : 0, fuse_w, fuse_b};
+    if (wu != nullptr && ks == 3 && !up && fuse_w == nullptr && (C1 == 0 || C1 == C0) && !unet_direct()) {     // Winograd-domain weights given: F(2x2, 3x3)
+        a.w = wu;
+        static const bool wide = [] { const char* e = getenv("IFD_WINO_WIDE"); return e != nullptr && e[0] == '1'; }();
+        if (HW >= 16) return (wide && Cout >= 64) ? launch_wino<2, 4>(a, n_img, s) : launch_wino<2, 2>(a, n_img, s);
+        return launch_wino<1, 4>(a, n_img, s);
+    }
     if (fuse_w != nullptr) {
         if (HW < 16 || ks != 3 || up || Cout != 32) return hipErrorInvalidValue;
         return launch_conv<16, 4, 1, 3, false, true, IFD_UNET_PW>(a, n_img, s);
@@ -267,23 +634,23 @@ hipError_t launch_unet(const UNetWeights& W, const float* x, float* out, float* 
     hipError_t e;
 #define IFD_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
     // encoder pathway (DownConv, unet.py:66-72): conv-relu, conv-relu, pool (not on the last level)
-    IFD_TRY(conv(x, 32, nullptr, 0, W.down_w[0][0], W.down_b[0][0], d0a, nullptr, 64, 32, 3, false, true, n_img, s));
-    IFD_TRY(conv(d0a, 32, nullptr, 0, W.down_w[0][1], W.down_b[0][1], d0, p1, 64, 32, 3, false, true, n_img, s));
-    IFD_TRY(conv(p1, 32, nullptr, 0, W.down_w[1][0], W.down_b[1][0], d1a, nullptr, 32, 64, 3, false, true, n_img, s));
-    IFD_TRY(conv(d1a, 64, nullptr, 0, W.down_w[1][1], W.down_b[1][1], d1, p2, 32, 64, 3, false, true, n_img, s));
-    IFD_TRY(conv(p2, 64, nullptr, 0, W.down_w[2][0], W.down_b[2][0], d2a, nullptr, 16, 128, 3, false, true, n_img, s));
-    IFD_TRY(conv(d2a, 128, nullptr, 0, W.down_w[2][1], W.down_b[2][1], d2, p3, 16, 128, 3, false, true, n_img, s));
-    IFD_TRY(conv(p3, 128, nullptr, 0, W.down_w[3][0], W.down_b[3][0], d3a, nullptr, 8, 256, 3, false, true, n_img, s));
-    IFD_TRY(conv(d3a, 256, nullptr, 0, W.down_w[3][1], W.down_b[3][1], d3, nullptr, 8, 256, 3, false, true, n_img, s));
+    IFD_TRY(conv(x, 32, nullptr, 0, W.down_w[0][0], W.down_b[0][0], d0a, nullptr, 64, 32, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[0][0]));
+    IFD_TRY(conv(d0a, 32, nullptr, 0, W.down_w[0][1], W.down_b[0][1], d0, p1, 64, 32, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[0][1]));
+    IFD_TRY(conv(p1, 32, nullptr, 0, W.down_w[1][0], W.down_b[1][0], d1a, nullptr, 32, 64, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[1][0]));
+    IFD_TRY(conv(d1a, 64, nullptr, 0, W.down_w[1][1], W.down_b[1][1], d1, p2, 32, 64, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[1][1]));
+    IFD_TRY(conv(p2, 64, nullptr, 0, W.down_w[2][0], W.down_b[2][0], d2a, nullptr, 16, 128, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[2][0]));
+    IFD_TRY(conv(d2a, 128, nullptr, 0, W.down_w[2][1], W.down_b[2][1], d2, p3, 16, 128, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[2][1]));
+    IFD_TRY(conv(p3, 128, nullptr, 0, W.down_w[3][0], W.down_b[3][0], d3a, nullptr, 8, 256, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[3][0]));
+    IFD_TRY(conv(d3a, 256, nullptr, 0, W.down_w[3][1], W.down_b[3][1], d3, nullptr, 8, 256, 3, false, true, n_img, s, nullptr, nullptr, W.down_u[3][1]));
     // decoder pathway (UpConv, unet.py:101-114): upconv, cat(up, skip), conv-relu, conv-relu
     IFD_TRY(conv(d3, 256, nullptr, 0, W.up_t_w[0], W.up_t_b[0], u0up, nullptr, 8, 128, 1, true, false, n_img, s));
-    IFD_TRY(conv(u0up, 128, d2, 128, W.up_w[0][0], W.up_b[0][0], u0a, nullptr, 16, 128, 3, false, true, n_img, s));
-    IFD_TRY(conv(u0a, 128, nullptr, 0, W.up_w[0][1], W.up_b[0][1], u0, nullptr, 16, 128, 3, false, true, n_img, s));
+    IFD_TRY(conv(u0up, 128, d2, 128, W.up_w[0][0], W.up_b[0][0], u0a, nullptr, 16, 128, 3, false, true, n_img, s, nullptr, nullptr, W.up_u[0][0]));
+    IFD_TRY(conv(u0a, 128, nullptr, 0, W.up_w[0][1], W.up_b[0][1], u0, nullptr, 16, 128, 3, false, true, n_img, s, nullptr, nullptr, W.up_u[0][1]));
     IFD_TRY(conv(u0, 128, nullptr, 0, W.up_t_w[1], W.up_t_b[1], u1up, nullptr, 16, 64, 1, true, false, n_img, s));
-    IFD_TRY(conv(u1up, 64, d1, 64, W.up_w[1][0], W.up_b[1][0], u1a, nullptr, 32, 64, 3, false, true, n_img, s));
-    IFD_TRY(conv(u1a, 64, nullptr, 0, W.up_w[1][1], W.up_b[1][1], u1, nullptr, 32, 64, 3, false, true, n_img, s));
+    IFD_TRY(conv(u1up, 64, d1, 64, W.up_w[1][0], W.up_b[1][0], u1a, nullptr, 32, 64, 3, false, true, n_img, s, nullptr, nullptr, W.up_u[1][0]));
+    IFD_TRY(conv(u1a, 64, nullptr, 0, W.up_w[1][1], W.up_b[1][1], u1, nullptr, 32, 64, 3, false, true, n_img, s, nullptr, nullptr, W.up_u[1][1]));
     IFD_TRY(conv(u1, 64, nullptr, 0, W.up_t_w[2], W.up_t_b[2], u2up, nullptr, 32, 32, 1, true, false, n_img, s));
-    IFD_TRY(conv(u2up, 32, d0, 32, W.up_w[2][0], W.up_b[2][0], u2a, nullptr, 64, 32, 3, false, true, n_img, s));
+    IFD_TRY(conv(u2up, 32, d0, 32, W.up_w[2][0], W.up_b[2][0], u2a, nullptr, 64, 32, 3, false, true, n_img, s, nullptr, nullptr, W.up_u[2][0]));
     // last conv-relu with conv_final (conv1x1, unet.py:238) fused into its epilogue
     IFD_TRY(conv(u2a, 32, nullptr, 0, W.up_w[2][1], W.up_b[2][1], out, nullptr, 64, 32, 3, false, true, n_img, s, W.fin_w,
                  W.fin_b));

@@ -6,7 +6,7 @@ tail -1 /tmp/ul.log
 python - <<'P'
 import csv, glob
 f = glob.glob('/tmp/ul/**/*kernel_trace.csv', recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if 'conv_kernel' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(f)) if 'conv_kernel' in r['Kernel_Name'] or 'wino_kernel' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 last = rows[-17:]
 names = "d0a d0 d1a d1 d2a d2 d3a d3 up0 u0a u0 up1 u1a u1 up2 u2a u2+fin".split()
