@@ -260,9 +260,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wino_rsrc(const float* p, unsi
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <int TG, int CG>
+// FUSE (TG = CG = 2, Cout = 32): a following conv1x1 (32 -> 32, bias, no ReLU: conv_final, unet.py:238) is applied to the block's
+// activated 16 x 8 pixel tile before it leaves the CU - the tile goes through LDS once (the V buffer is free between an item's
+// last MFMA and the next transform) to turn the accumulator layout (lane = channel) into the A-operand layout (lane = pixel),
+// 32 more MFMAs per wave, and the intermediate tensor is neither written nor read back.
+template <int TG, int CG, bool FUSE = false>
 __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kernel(ConvArgs a, int items_per_block, int n_items) {
     static_assert((TG == 1 || TG == 2) && (CG == 2 || CG == 4), "4 or 8 waves");
+    static_assert(!FUSE || (TG == 2 && CG == 2), "FUSE: 128 pixels x 32 channels per block");
     constexpr int NT = 16 * TG, NCO = 16 * CG, NTHR = 64 * TG * CG;
     constexpr int RPT = 4 / CG;                  // xi rows per thread in the input transform: NT * 4 * (4 / RPT) = NTHR threads
     constexpr int NROW = RPT + 1;                // patch rows a thread needs for them
@@ -501,6 +506,16 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
         const __amdgpu_buffer_rsrc_t ors = wino_rsrc(a.out + (size_t)n * a.H * a.W * a.Cout, out_bytes);
         const __amdgpu_buffer_rsrc_t prs = wino_rsrc(a.pool_out != nullptr ? a.pool_out + (size_t)n * (a.H / 2) * (a.W / 2) * a.Cout : a.out, out_bytes / 4u);
         const int st_reg = (y0 * a.W + x0) * a.Cout * 4, pl_reg = ((y0 / 2) * (a.W / 2) + x0 / 2) * a.Cout * 4;
+        constexpr int TRS = 36;                                            // row of the activated tile T[128 pixels][32 ch] (floats)
+        // (Sending EVERY layer's tile through LDS - T[pixel][32 ch], then 16-byte stores of whole 128-byte pixel rows instead of 20
+        // four-byte stores per lane from the accumulator layout - was measured: 53.3 against 50.0 ms for the U-Net, the two extra
+        // barriers per item cost more than the address unit saves; -DIFD_WINO_STORE_LDS.)
+#ifdef IFD_WINO_STORE_LDS
+        constexpr bool VIA_LDS = TG == 2 && CG == 2;
+#else
+        constexpr bool VIA_LDS = FUSE;
+#endif
+        if (VIA_LDS) __syncthreads();                                      // every wave's MFMAs have read s_v: it becomes T
 #pragma unroll
         for (int tx = 0; tx < 4; ++tx) {
             float t0[4], t1[4];
@@ -519,15 +534,59 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
                     float v = y[ya][xb] + bias;
                     if (a.relu) v = fmaxf(v, 0.f);
                     y[ya][xb] = v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, st_lane, st_reg + ((ya * a.W + 2 * tx + xb) * a.Cout) * 4, 0);
+                    if (VIA_LDS) s_v[((2 * kq + ya) * 16 + 8 * tg + 2 * tx + xb) * TRS + cg * 16 + r] = v;
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, st_lane, st_reg + ((ya * a.W + 2 * tx + xb) * a.Cout) * 4, 0);
                 }
-            if (a.pool_out != nullptr)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]))), prs,
-                                                      pl_lane, pl_reg + tx * a.Cout * 4, 0);
+            if (a.pool_out != nullptr) {
+                const float pv = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+                if (VIA_LDS) s_v[(128 + kq * 8 + 4 * tg + tx) * TRS + cg * 16 + r] = pv;
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), prs, pl_lane, pl_reg + tx * a.Cout * 4, 0);
+            }
+        }
+        if constexpr (VIA_LDS && !FUSE) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = tid + k * 256, px = idx >> 3, pc = idx & 7;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_v + px * TRS + 4 * pc);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, v), ors, (co0 + 4 * pc) * 4,
+                                                       st_reg + (((px >> 4) * a.W + (px & 15)) * a.Cout) * 4, 0);
+            }
+            if (a.pool_out != nullptr) {
+                const int px = tid >> 3, pc = tid & 7;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_v + (128 + px) * TRS + 4 * pc);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, v), prs, (co0 + 4 * pc) * 4,
+                                                       pl_reg + (((px >> 3) * (a.W / 2) + (px & 7)) * a.Cout) * 4, 0);
+            }
+        }
+        if constexpr (FUSE) {
+            // out[px][co2] = fuse_b[co2] + sum_c T[px][c] fuse_w[c][co2]: wave w takes the pixel rows 2 w, 2 w + 1 of the tile (16
+            // pixels each) and both groups of 16 output channels; k-slot (s, kq) <-> channel 8 kq + s on both operands
+            __syncthreads();
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                float bw[8];
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) bw[k8] = a.fuse_w[(8 * kq + k8) * 32 + 16 * c2 + r];
+                const float fb = a.fuse_b[16 * c2 + r];
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg) {
+                    const int ly = 2 * wave + pg;
+                    const float* tp = s_v + (ly * 16 + r) * TRS + 8 * kq;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(tp), a1 = *reinterpret_cast<const f32x4*>(tp + 4);
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) o = __builtin_amdgcn_mfma_f32_16x16x4f32(k8 < 4 ? a0[k8] : a1[k8 - 4], bw[k8], o, 0, 0, 0);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)       // D: lane (co2 = 16 c2 + r, kq), register rr <-> pixel column 4 kq + rr of row ly
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[rr] + fb), ors, (16 * c2 + r) * 4,
+                                                              st_reg + ((ly * a.W + 4 * kq + rr) * a.Cout) * 4, 0);
+                }
+            }
         }
     }
 #ifdef IFD_WINO_PROF
-    if (lane == 0 && a.fuse_b != nullptr) {
+    if (!FUSE && lane == 0 && a.fuse_b != nullptr) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.fuse_b));
         for (int i = 0; i < 6; ++i) atomicAdd(o + i, pt[i]);
         atomicAdd(o + 6, (unsigned long long)n_steps);
@@ -538,7 +597,7 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
 #ifndef IFD_WINO_ITEMS
 #define IFD_WINO_ITEMS 16             // (image, region) work items per block
 #endif
-template <int TG, int CG>
+template <int TG, int CG, bool FUSE = false>
 static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
 #ifdef IFD_WINO_OCC1
     constexpr size_t LDS = 96 * 1024;
@@ -551,12 +610,16 @@ static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
     const int per = max(1, min(IFD_WINO_ITEMS, (int)((long long)n_items * gy / 6144)));
     const dim3 grid((n_items + per - 1) / per, gy, 1);
 #ifdef IFD_WINO_PROF
+    if (FUSE) {
+        hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
+        return hipGetLastError();
+    }
     static unsigned long long* dbg = nullptr;
     if (dbg == nullptr) (void)hipMalloc(reinterpret_cast<void**>(&dbg), 64);
     (void)hipMemsetAsync(dbg, 0, 64, s);
     ConvArgs b = a;
     b.fuse_b = reinterpret_cast<const float*>(dbg);
-    hipLaunchKernelGGL((wino_kernel<TG, CG>), grid, dim3(64 * TG * CG), LDS, s, b, per, n_items);
+    hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE>), grid, dim3(64 * TG * CG), LDS, s, b, per, n_items);
     unsigned long long h[8];
     (void)hipMemcpyAsync(h, dbg, 56, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
@@ -565,7 +628,7 @@ static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
             TG, CG, a.H, a.C0 + a.C1, a.Cout, h[0] / ws, h[1] / ws, h[2] / ws, h[3] / ws, h[4] / ws, h[5] / ws);
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((wino_kernel<TG, CG>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
+    hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
     return hipGetLastError();
 #endif
 }
@@ -574,6 +637,8 @@ hipError_t configure_unet_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * 96 * 4);
 }
@@ -593,8 +658,12 @@ static hipError_t conv(const float* in0, int C0, const float* in1, int C1, const
                        float* pool_out, int HW, int Cout, int ks, bool up, bool relu, int n_img, hipStream_t s,
                        const float* fuse_w = nullptr, const float* fuse_b = nullptr, const float* wu = nullptr) {
     ConvArgs a{in0, in1, w, b, out, pool_out, HW, HW, C0, C1, Cout, relu ? 1 : 0, fuse_w, fuse_b};
-    if (wu != nullptr && ks == 3 && !up && fuse_w == nullptr && (C1 == 0 || C1 == C0) && !unet_direct()) {     // Winograd-domain weights given: F(2x2, 3x3)
+    if (wu != nullptr && ks == 3 && !up && (C1 == 0 || C1 == C0) && !unet_direct()) {     // Winograd-domain weights given: F(2x2, 3x3)
         a.w = wu;
+        if (fuse_w != nullptr) {
+            if (HW < 16 || Cout != 32) return hipErrorInvalidValue;
+            return launch_wino<2, 2, true>(a, n_img, s);
+        }
         static const bool wide = [] { const char* e = getenv("IFD_WINO_WIDE"); return e != nullptr && e[0] == '1'; }();
         if (HW >= 16) return (wide && Cout >= 64) ? launch_wino<2, 4>(a, n_img, s) : launch_wino<2, 2>(a, n_img, s);
         return launch_wino<1, 4>(a, n_img, s);
@@ -653,7 +722,7 @@ hipError_t launch_unet(const UNetWeights& W, const float* x, float* out, float* 
     IFD_TRY(conv(u2up, 32, d0, 32, W.up_w[2][0], W.up_b[2][0], u2a, nullptr, 64, 32, 3, false, true, n_img, s, nullptr, nullptr, W.up_u[2][0]));
     // last conv-relu with conv_final (conv1x1, unet.py:238) fused into its epilogue
     IFD_TRY(conv(u2a, 32, nullptr, 0, W.up_w[2][1], W.up_b[2][1], out, nullptr, 64, 32, 3, false, true, n_img, s, W.fin_w,
-                 W.fin_b));
+                 W.fin_b, W.up_u[2][1]));
 #undef IFD_TRY
     return hipSuccess;
 }

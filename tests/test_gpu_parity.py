@@ -1899,3 +1899,19 @@ def test_trained_like_pipeline_lists_and_split(trained):
     print("trained-like, 301 steps: |occupancy probability - 0.2| %.3f -> %.3f; %.1f list rebuilds per cloud, ring on %.2f of the wave-steps"
           % (np.abs(p0 - 0.2).mean(), np.abs(p1 - 0.2).mean(), c["knn_rebuilds"] / 64.0, c["knn_ring_evals"] / (64.0 * 301)))
     assert np.abs(p1 - 0.2).mean() < 0.5 * np.abs(p0 - 0.2).mean()          # the points moved onto the iso-surface
+
+
+@pytest.mark.gpu
+def test_winograd_unet_against_the_implicit_gemm_unet():
+    """The 3x3 layers of the U-Net run in the Winograd F(2x2, 3x3) domain (csrc/unet.hip wino_kernel; reference:
+    src/encoder/unet.py:48-57 conv3x3).  IFD_UNET_DIRECT=1 sends them through the implicit-GEMM kernel - the plain
+    nine-tap sum - instead: the two must agree to float32 rounding of the transforms (measured 7.5e-7 of the planes'
+    maximum; F(2x2, 3x3) has transform constants 0, +-1, 1/2 only)."""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "wino_check.py"), "48"], capture_output=True, text=True,
+                       cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"max \|winograd - direct\| / max \|direct\| = ([0-9.e+-]+) .*any nan (\w+)", r.stdout)
+    assert m, r.stdout + r.stderr
+    assert m.group(2) == "False" and float(m.group(1)) < 3e-6, r.stdout
