@@ -420,7 +420,6 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
 #else
 #define WP(i)
 #endif
-    const bool slot_odd = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0;       // HW_ID.WAVE_ID bit 0: the wave slot on this SIMD
     int e_n = f_n, e_ry = f_ry, e_rx = f_rx;       // the item whose chunks are being accumulated: the block's first
     fetch(n_steps > 0);
     int chunk = 0;
@@ -480,18 +479,9 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         };
-        // Wave priority while the wave streams MFMAs - and a DIFFERENT one for the two waves that share a SIMD (two blocks per
-        // CU; the wave slot's low bit): measured per phase (-DIFD_WINO_PROF), the two blocks of a CU otherwise fall into step -
-        // both in their MFMA phases, interleaving (4.9 k cycles for 2 k of MFMAs), then both in their transform / barrier
-        // phases with the matrix pipe idle.  With the priorities one wave takes the pipe, finishes first and leaves for its
-        // transform while the other streams: the blocks alternate.
-#ifndef IFD_WINO_NOPRIO
-        if (slot_odd) asm volatile("s_setprio 3"); else asm volatile("s_setprio 2");
-#endif
+        // (Wave priorities for the MFMA phase - also a different one for each of the two waves that share a SIMD, so that the
+        // two blocks of a CU alternate instead of falling into step - measured nothing: 50.07 against 50.16 ms.)
         if (chunk == 0) mfma_chunk(std::true_type{}); else mfma_chunk(std::false_type{});
-#ifndef IFD_WINO_NOPRIO
-        asm volatile("s_setprio 0");
-#endif
         WP(4);
         if (++chunk != n_chunks) continue;
         chunk = 0;
@@ -639,8 +629,7 @@ hipError_t configure_unet_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * 96 * 4);
+    return e;
 }
 
 // -DIFD_UNET_DIRECT / env IFD_UNET_DIRECT=1: every 3x3 layer on the implicit-GEMM kernel (A/B and validation of the Winograd path)
@@ -664,8 +653,8 @@ static hipError_t conv(const float* in0, int C0, const float* in1, int C1, const
             if (HW < 16 || Cout != 32) return hipErrorInvalidValue;
             return launch_wino<2, 2, true>(a, n_img, s);
         }
-        static const bool wide = [] { const char* e = getenv("IFD_WINO_WIDE"); return e != nullptr && e[0] == '1'; }();
-        if (HW >= 16) return (wide && Cout >= 64) ? launch_wino<2, 4>(a, n_img, s) : launch_wino<2, 2>(a, n_img, s);
+        // (8-wave blocks of 32 tiles x 64 channels - the input transform shared by twice the MFMAs - measured 51.3 against 50.1 ms)
+        if (HW >= 16) return launch_wino<2, 2>(a, n_img, s);
         return launch_wino<1, 4>(a, n_img, s);
     }
     if (fuse_w != nullptr) {
