@@ -479,6 +479,10 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         };
+        // (The weight slab straight into LDS with `buffer_load ... lds` - no staging registers, half the bytes on the VGPR -> LDS
+        // store path that bounds the transform phase, 172 instead of 206 VGPRs - was built and measured: 52.8 against 50.2 ms.
+        // The slab can only be requested behind the first barrier of its own step and must have landed before the second: its
+        // L2 round trip lies open in the transform phase, while the register-staged form fetches it a whole step ahead.)
         // (Wave priorities for the MFMA phase - also a different one for each of the two waves that share a SIMD, so that the
         // two blocks of a CU alternate instead of falling into step - measured nothing: 50.07 against 50.16 ms.)
         if (chunk == 0) mfma_chunk(std::true_type{}); else mfma_chunk(std::false_type{});
