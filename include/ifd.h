@@ -143,7 +143,9 @@ int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
 
 /* The shared 2-D U-Net applied to the three planes of every cloud (pointnet.py:82-84 -> src/encoder/unet.py:225-239):
  * planes_pre [B,3,64,64,32] -> planes [B,3,64,64,32], both channel-last.  Uses context-owned scratch
- * (about 15 MB per cloud, grown on demand). */
+ * (about 15 MB per cloud, grown on demand).  The 3x3 convolutions (unet.py:48-57) are evaluated in the Winograd
+ * F(2x2, 3x3) domain in float32 (within 1e-6 of the planes' maximum of the plain nine-tap sum; fixed summation order,
+ * independent of B); environment IFD_UNET_DIRECT=1 selects the nine-tap implicit-GEMM kernels instead (validation). */
 int ifd_unet(ifd_ctx* ctx, const float* planes_pre, int B, float* planes, void* stream);
 
 /* generator.model.encode_inputs(x) (ConvONet/opt_defense.py:300 -> src/conv_onet/models/__init__.py:52 ->
