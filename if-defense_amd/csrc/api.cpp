@@ -94,6 +94,7 @@ struct ifd_ctx {
     float* d_w = nullptr;          // the whole canonical weight vector on the device (encoder kernels index it)
     EncPointOffsets eo{};
     float* d_unet = nullptr;       // re-packed U-Net weights ([tap][Cin][Cout])
+    float* d_enc_img = nullptr;    // aligned copy of the point-net weights (encoder.hip build_enc_image)
     UNetWeights uw{};
     void* ws_enc = nullptr;        // encoder scratch (pre-U-Net planes + U-Net activations), grown on demand
     size_t ws_enc_bytes = 0;
@@ -430,6 +431,12 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         }
         u.fin_w = d + P.fin_w; u.fin_b = d + P.fin_b;
     }
+    if (e == hipSuccess) {
+        std::vector<float> img((size_t)enc_image_floats());
+        build_enc_image(ctx->w.data(), ctx->eo, img.data());
+        e = hipMalloc(reinterpret_cast<void**>(&ctx->d_enc_img), img.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_enc_img, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = configure_encoder_kernels();
     if (e == hipSuccess) e = configure_unet_kernels();
     if (e == hipSuccess) e = configure_prep_kernels();
@@ -441,6 +448,8 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_w) (void)hipFree(ctx->d_w);
         if (ctx->d_unet) (void)hipFree(ctx->d_unet);
+    if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
+        if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
         delete ctx;
         return nullptr;
     }
@@ -457,6 +466,7 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_w) (void)hipFree(ctx->d_w);
     if (ctx->d_unet) (void)hipFree(ctx->d_unet);
+    if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
     if (ctx->ws_enc) (void)hipFree(ctx->ws_enc);
     if (ctx->d_onet_img) (void)hipFree(ctx->d_onet_img);
     if (ctx->d_onet_small) (void)hipFree(ctx->d_onet_small);
@@ -499,9 +509,7 @@ int ifd_encode_points(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
     if (!sel || !planes_pre || B < 1 || Tmax < 1 || Tmax > 1024)
         return fail(ctx, IFD_ERR_ARG, "ifd_encode_points: bad argument (1 <= Tmax <= 1024)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(planes_pre, 0, (size_t)B * CLOUD_PLANE_FLOATS * sizeof(float), s);
-    if (e == hipSuccess)
-        e = launch_encode_points(ctx->d_w, ctx->eo, sel, t_per_cloud, B, Tmax, planes_pre, c_points, ctx->dc, s);
+    hipError_t e = launch_encode_points(ctx->d_w, ctx->eo, ctx->d_enc_img, sel, t_per_cloud, B, Tmax, planes_pre, c_points, ctx->dc, s);
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_encode_points", e);
 }
 
@@ -529,8 +537,7 @@ int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_encode_planes workspace", e);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* pre = static_cast<float*>(ctx->ws_enc);
-    e = hipMemsetAsync(pre, 0, pre_floats * sizeof(float), s);
-    if (e == hipSuccess) e = launch_encode_points(ctx->d_w, ctx->eo, sel, t_per_cloud, B, Tmax, pre, nullptr, ctx->dc, s);
+    e = launch_encode_points(ctx->d_w, ctx->eo, ctx->d_enc_img, sel, t_per_cloud, B, Tmax, pre, nullptr, ctx->dc, s);
     if (e == hipSuccess) e = launch_unet(ctx->uw, pre, planes, pre + pre_floats, 3 * B, s);
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_encode_planes", e);
 }

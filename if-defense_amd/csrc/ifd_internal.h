@@ -30,8 +30,11 @@ struct EncPointOffsets {
 };
 
 hipError_t configure_encoder_kernels();
-hipError_t launch_encode_points(const float* w, const EncPointOffsets& eo, const float* sel, const int* t_per_cloud,
-                                int B, int Tmax, float* planes, float* c_out, DecConst dc, hipStream_t s);
+int enc_image_floats();
+void build_enc_image(const float* w, const EncPointOffsets& eo, float* img);      // host: aligned point-net weights (encoder.hip)
+// zero-fills planes itself
+hipError_t launch_encode_points(const float* w, const EncPointOffsets& eo, const float* enc_img, const float* sel,
+                                const int* t_per_cloud, int B, int Tmax, float* planes, float* c_out, DecConst dc, hipStream_t s);
 
 // device pointers to the re-packed ([tap][Cin][Cout]) U-Net weights
 struct UNetWeights {

@@ -1909,9 +1909,24 @@ def test_winograd_unet_against_the_implicit_gemm_unet():
     maximum; F(2x2, 3x3) has transform constants 0, +-1, 1/2 only)."""
     import subprocess, sys, os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "wino_check.py"), "48"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "wino_check.py"), "16"], capture_output=True, text=True,
                        cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"max \|winograd - direct\| / max \|direct\| = ([0-9.e+-]+) .*any nan (\w+)", r.stdout)
     assert m, r.stdout + r.stderr
     assert m.group(2) == "False" and float(m.group(1)) < 3e-6, r.stdout
+
+
+@pytest.mark.gpu
+def test_mfma_point_encoder_against_the_thread_per_point_encoder():
+    """encode_points runs its linear layers on the matrix pipe (csrc/encoder.hip encode_points_mfma_kernel; reference:
+    src/encoder/pointnet.py:124-168).  IFD_ENC_VALU=1 selects the thread-per-point kernel with its sequential
+    fused-multiply-add order instead: same occupied cells, features equal to float32 rounding of the sums."""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "enc_check.py"), "16"], capture_output=True, text=True,
+                       cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"max \|mfma - valu\| / max \|valu\| = ([0-9.e+-]+) .*occupied cells equal (\w+), any nan (\w+)", r.stdout)
+    assert m, r.stdout + r.stderr
+    assert m.group(2) == "True" and m.group(3) == "False" and float(m.group(1)) < 5e-6, r.stdout
