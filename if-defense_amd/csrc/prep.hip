@@ -163,10 +163,27 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
     const uint8_t* km = keep ? keep + (size_t)b * K : nullptr;
 
     // ---- stable compaction of the kept points (boolean-mask indexing keeps the original order) --------
-    if (tid == 0) {
-        int n = 0;
-        for (int i = 0; i < K; ++i) { POS[i] = n; n += (!km || km[i]) ? 1 : 0; }
-        *s_n = n;
+    // (exclusive prefix sum of the keep flags, 1024 points at a time: ballot + popcount inside a wave, the 16 wave totals through
+    // LDS.  Rounds 1-3 had thread 0 walk the mask: 1024 dependent global byte loads and LDS stores in front of everything else.)
+    {
+        int* wtot = reinterpret_cast<int*>(scratch);                  // [16] wave totals of the current chunk
+        int base = 0;
+        for (int c0 = 0; c0 < K; c0 += PREP_THREADS) {
+            const int i = c0 + tid;
+            const bool kept = i < K && (!km || km[i]);
+            const unsigned long long m = __ballot(kept);
+            const int lane = tid & 63, wave = tid >> 6;
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wtot[wave] = __popcll(m);
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < PREP_THREADS / 64; ++w) { const int t = wtot[w]; woff += w < wave ? t : 0; tot += t; }
+            if (i < K) POS[i] = base + woff + before;
+            base += tot;
+            __syncthreads();
+        }
+        if (tid == 0) *s_n = base;
     }
     __syncthreads();
     const int n = *s_n;
