@@ -526,6 +526,9 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
         // store path that bounds the transform phase, 172 instead of 206 VGPRs - was built and measured: 52.8 against 50.2 ms.
         // The slab can only be requested behind the first barrier of its own step and must have landed before the second: its
         // L2 round trip lies open in the transform phase, while the register-staged form fetches it a whole step ahead.)
+        // (Steps of 8 input channels instead of 16 - 32 KB of LDS and 166 VGPRs per block, THREE blocks per CU, 8-byte operand
+        // reads - was built and measured: 49.9 against 49.7 ms.  Occupancy is not what holds the kernel at 0.57 of the matrix
+        // pipe: 2.4 other vector instructions per MFMA share that pipe, and the staging bytes per MFMA do not change.)
         // (Wave priorities for the MFMA phase - also a different one for each of the two waves that share a SIMD, so that the
         // two blocks of a CU alternate instead of falling into step - measured nothing: 50.07 against 50.16 ms.)
         if (chunk == 0) mfma_chunk(std::true_type{}); else mfma_chunk(std::false_type{});
