@@ -264,26 +264,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wino_rsrc(const float* p, unsi
 // activated 16 x 8 pixel tile before it leaves the CU - the tile goes through LDS once (the V buffer is free between an item's
 // last MFMA and the next transform) to turn the accumulator layout (lane = channel) into the A-operand layout (lane = pixel),
 // 32 more MFMAs per wave, and the intermediate tensor is neither written nor read back.
-// CK: input channels per step, 16 or 8.  With 8 (TG = CG = 2 only) a block holds 32 KB of LDS and ~165 VGPRs: three blocks per CU
-// instead of two, half the work between two barriers; the operands are 8-byte reads (two k-steps each).
-template <int TG, int CG, bool FUSE = false, int CK = 16>
-__global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1)) void wino_kernel(ConvArgs a, int items_per_block, int n_items) {
+template <int TG, int CG, bool FUSE = false>
+__global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kernel(ConvArgs a, int items_per_block, int n_items) {
     static_assert((TG == 1 || TG == 2) && (CG == 2 || CG == 4), "4 or 8 waves");
     static_assert(!FUSE || (TG == 2 && CG == 2), "FUSE: 128 pixels x 32 channels per block");
-    static_assert(CK == 16 || (CK == 8 && TG == 2 && CG == 2), "8-channel steps: 32 tiles x 32 channels");
     constexpr int NT = 16 * TG, NCO = 16 * CG, NTHR = 64 * TG * CG;
-    constexpr int PR = CK / 4;                   // 16-byte pieces per LDS row
-    constexpr int RPT = (4 * PR * NT) / NTHR;    // xi rows per thread in the input transform: NT * PR * (4 / RPT) = NTHR threads
+    constexpr int RPT = 4 / CG;                  // xi rows per thread in the input transform: NT * 4 * (4 / RPT) = NTHR threads
     constexpr int NROW = RPT + 1;                // patch rows a thread needs for them
     extern __shared__ __attribute__((aligned(16))) float wsm[];
-    float* s_v = wsm;                            // [16 xi][NT tiles][CK ch]
-    float* s_u = wsm + 16 * NT * CK;             // [16 xi][NCO couts][CK ch]
+    float* s_v = wsm;                            // [16 xi][NT tiles][16 ch]
+    float* s_u = wsm + 16 * NT * 16;             // [16 xi][NCO couts][16 ch]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tg = wave % TG, cg = wave / TG;
     const int regions_x = a.W / (8 * TG), regions = regions_x * (a.H / 8);
     const int co0 = (int)blockIdx.y * NCO;
-    const int Cin = a.C0 + a.C1, n_chunks = Cin / CK;
+    const int Cin = a.C0 + a.C1, n_chunks = Cin / 16;
     // A block walks `items_per_block` work items (image, region) and their chunks of 16 input channels as ONE sequence of steps,
     // the global loads of step k + 1 in flight under the MFMAs of step k: the memory latency is paid once per block, not once
     // per region (a 64^2 layer with 32 input channels has two chunks per region).
@@ -293,16 +289,13 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
 
     // ---- the thread's share of the input transform: tile ut, channel piece ucq, xi rows [RPT uh, RPT uh + RPT) ----
     // (uh is wave-uniform: 4 NT threads per value)
-    const int ucq = tid % PR, ut = (tid / PR) % NT;
-    const int uh = __builtin_amdgcn_readfirstlane(tid / (PR * NT));
+    const int ucq = tid & 3, ut = (tid >> 2) % NT;
+    const int uh = __builtin_amdgcn_readfirstlane(tid / (4 * NT));
     const int utt = ut & 15, uty = utt >> 2, utx = utt & 3;
     const int pyo = 2 * uty - 1, pxo = 8 * (ut >> 4) + 2 * utx - 1;       // top-left of the 4x4 patch inside the region
     // patch rows: RPT 2: uh .. uh + 2; RPT 1: {0 | 1, 2 | 3}
     // Loads are buffer loads (the image is the buffer, 32-bit byte offsets, out-of-image taps get an offset beyond the buffer
     // and come back as the zero padding): no 64-bit address arithmetic, no branches around the loads.
-    // piece p of row r sits at p ^ sw(r): CK 16: four pieces, 16-byte operand reads (wswz); CK 8: two pieces, 8-byte reads whose
-    // 32-lane groups cover rows r and r + 8 on the same banks - the pieces of the rows 8 ... 15 are swapped
-    auto sw = [](int r) { return CK == 16 ? wswz(r) : ((r >> 3) & 1); };
     const int cs = a.C0;                                                   // (both sources of a concat layer have C0 channels: conv())
     const unsigned int img_bytes = (unsigned int)(a.H * a.W * cs) * 4u;
     int yrel[NROW], xrel[4], poff[NROW][4];
@@ -314,12 +307,12 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
     for (int k = 0; k < NROW; ++k)
 #pragma unroll
         for (int x = 0; x < 4; ++x) poff[k][x] = ((yrel[k] * a.W + xrel[x]) * cs + 4 * ucq) * 4;
-    constexpr int W_IT = (16 * NCO * PR) / NTHR; // f32x4 pieces of the weight slab per thread
-    int woff[W_IT];                              // (the weights lie as [Cin / 16][xi][Cout][16]: an 8-channel step takes half of every row)
+    constexpr int W_IT = (16 * NCO * 4) / NTHR;  // f32x4 pieces of the weight slab per thread
+    int woff[W_IT];
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
         const int i = tid + it * NTHR;
-        const int cq = i % PR, nn = (i / PR) % NCO, xi = i / (PR * NCO);
+        const int cq = i & 3, nn = (i >> 2) % NCO, xi = i / (4 * NCO);
         woff[it] = ((xi * a.Cout + co0 + nn) * 16 + 4 * cq) * 4;
     }
     const __amdgpu_buffer_rsrc_t wrs = wino_rsrc(a.w, (unsigned int)(16 * Cin * a.Cout) * 4u);
@@ -329,7 +322,7 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
     int f_n = item0 / regions, f_ry = ((item0 % regions) / regions_x) * 8, f_rx = ((item0 % regions) % regions_x) * 8 * TG, f_c0 = 0;
     auto fetch = [&](bool live) {                  // live = false: nothing left to fetch - every tap out of range (the loads return 0)
         const int n = live ? f_n : 0, ry = f_ry, rx = f_rx, c0 = f_c0;
-        f_c0 += CK;
+        f_c0 += 16;
         if (f_c0 == Cin) {
             f_c0 = 0;
             f_rx += 8 * TG;
@@ -354,27 +347,27 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
                 rin[k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, off, 0, 0));
             }
         }
-        const int wbase = ((c0 / 16) * 16 * a.Cout * 16 + (c0 & 15)) * 4;                // [xi][Cout][16] of this chunk (+ 8: its second half)
+        const int wbase = (c0 / 16) * 16 * a.Cout * 16 * 4;                              // [xi][Cout][16] of this chunk
 #pragma unroll
         for (int it = 0; it < W_IT; ++it)
             rw[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[it], wbase, 0));
     };
     // B^T d B for the thread's xi rows: row combination first, then the columns; one 16-byte store per xi
-    float* const vdst = s_v + ut * CK + 4 * (ucq ^ sw(utt));
+    float* const vdst = s_v + ut * 16 + 4 * (ucq ^ wswz(utt));
     auto put_row = [&](int xr, const f32x4 (&R)[4]) {
         const f32x4 v0 = R[0] - R[2], v1 = R[1] + R[2], v2 = R[2] - R[1], v3 = R[1] - R[3];
-        float* d = vdst + (size_t)(4 * xr) * NT * CK;
+        float* d = vdst + (size_t)(4 * xr) * NT * 16;
         *reinterpret_cast<f32x4*>(d) = v0;
-        *reinterpret_cast<f32x4*>(d + NT * CK) = v1;
-        *reinterpret_cast<f32x4*>(d + 2 * NT * CK) = v2;
-        *reinterpret_cast<f32x4*>(d + 3 * NT * CK) = v3;
+        *reinterpret_cast<f32x4*>(d + NT * 16) = v1;
+        *reinterpret_cast<f32x4*>(d + 2 * NT * 16) = v2;
+        *reinterpret_cast<f32x4*>(d + 3 * NT * 16) = v3;
     };
     int udst[W_IT];
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
         const int i = tid + it * NTHR;
-        const int cq = i % PR, nn = (i / PR) % NCO, xi = i / (PR * NCO);
-        udst[it] = (xi * NCO + nn) * CK + 4 * (cq ^ sw(nn & 15));
+        const int cq = i & 3, nn = (i >> 2) % NCO, xi = i / (4 * NCO);
+        udst[it] = (xi * NCO + nn) * 16 + 4 * (cq ^ wswz(nn & 15));
     }
     auto transform = [&]() {
         f32x4 R[4];
@@ -413,9 +406,8 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
 
     f32x4 acc[16];
     const int r = lane & 15, kq = lane >> 4;
-    // CK 16: lane kq reads piece kq (four k-steps); CK 8: the 8 bytes {2 kq, 2 kq + 1} of the 8-float row (two k-steps)
-    const float* ap = s_v + (tg * 16 + r) * CK + (CK == 16 ? 4 * (kq ^ wswz(r)) : 2 * (kq ^ (2 * sw(r))));
-    const float* bp = s_u + (cg * 16 + r) * CK + (CK == 16 ? 4 * (kq ^ wswz(r)) : 2 * (kq ^ (2 * sw(r))));
+    const float* ap = s_v + (tg * 16 + r) * 16 + 4 * (kq ^ wswz(r));
+    const float* bp = s_u + (cg * 16 + r) * 16 + 4 * (kq ^ wswz(r));
     const int co = co0 + cg * 16 + r;
     const float bias = a.bias[co];
     const int st_lane = ((2 * kq * a.W + 8 * tg) * a.Cout + co) * 4;               // byte offset of the lane's first output pixel in its region
@@ -454,41 +446,6 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
         auto mfma_chunk = [&](auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
             fetch(step + 1 < n_steps);
-            if constexpr (CK == 8) {
-                // 16 xi x 2 k-steps: groups of four xi (eight MFMAs on four accumulator chains), the next group's eight 8-byte
-                // operand reads ahead of them
-                typedef float f32x2w __attribute__((ext_vector_type(2)));
-                f32x2w a8[2][4], b8[2][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a8[0][e] = *reinterpret_cast<const f32x2w*>(ap + e * NT * CK);
-                    b8[0][e] = *reinterpret_cast<const f32x2w*>(bp + e * NCO * CK);
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int cur = p & 1, nxt = cur ^ 1;
-                    if (p + 1 < 4) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a8[nxt][e] = *reinterpret_cast<const f32x2w*>(ap + (4 * p + 4 + e) * NT * CK);
-                            b8[nxt][e] = *reinterpret_cast<const f32x2w*>(bp + (4 * p + 4 + e) * NCO * CK);
-                        }
-                    }
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const f32x4 c = (FIRST && s2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[4 * p + e];
-                            acc[4 * p + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[cur][e][s2], b8[cur][e][s2], c, 0, 0, 0);
-                        }
-                    constexpr int NLD = NROW * 4 + W_IT;                  // global loads of a fetch, spread over the four groups
-                    if (p == 0) __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, NLD / 4, 0);
-                    if (p + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                }
-                return;
-            }
             f32x4 av[2][2], bv[2][2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -637,12 +594,12 @@ __global__ __launch_bounds__(64 * TG * CG, CK == 8 ? 3 : (TG * CG == 4 ? 2 : 1))
 #ifndef IFD_WINO_ITEMS
 #define IFD_WINO_ITEMS 16             // (image, region) work items per block
 #endif
-template <int TG, int CG, bool FUSE = false, int CK = 16>
+template <int TG, int CG, bool FUSE = false>
 static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
 #ifdef IFD_WINO_OCC1
     constexpr size_t LDS = 96 * 1024;
 #else
-    constexpr size_t LDS = (size_t)16 * CK * (16 * TG + 16 * CG) * sizeof(float);
+    constexpr size_t LDS = (size_t)16 * 16 * (16 * TG + 16 * CG) * sizeof(float);
 #endif
     const int n_items = n_img * (a.H / 8) * (a.W / (8 * TG));
     // up to IFD_WINO_ITEMS items per block, fewer where that would leave less than ~12 blocks per block slot of the chip
@@ -651,7 +608,7 @@ static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
     const dim3 grid((n_items + per - 1) / per, gy, 1);
 #ifdef IFD_WINO_PROF
     if (FUSE) {
-        hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE, CK>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
+        hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
         return hipGetLastError();
     }
     static unsigned long long* dbg = nullptr;
@@ -659,7 +616,7 @@ static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
     (void)hipMemsetAsync(dbg, 0, 64, s);
     ConvArgs b = a;
     b.fuse_b = reinterpret_cast<const float*>(dbg);
-    hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE, CK>), grid, dim3(64 * TG * CG), LDS, s, b, per, n_items);
+    hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE>), grid, dim3(64 * TG * CG), LDS, s, b, per, n_items);
     unsigned long long h[8];
     (void)hipMemcpyAsync(h, dbg, 56, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
@@ -668,7 +625,7 @@ static hipError_t launch_wino(const ConvArgs& a, int n_img, hipStream_t s) {
             TG, CG, a.H, a.C0 + a.C1, a.Cout, h[0] / ws, h[1] / ws, h[2] / ws, h[3] / ws, h[4] / ws, h[5] / ws);
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE, CK>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
+    hipLaunchKernelGGL((wino_kernel<TG, CG, FUSE>), grid, dim3(64 * TG * CG), LDS, s, a, per, n_items);
     return hipGetLastError();
 #endif
 }
@@ -704,8 +661,6 @@ static hipError_t conv(const float* in0, int C0, const float* in1, int C1, const
             return launch_wino<2, 2, true>(a, n_img, s);
         }
         // (8-wave blocks of 32 tiles x 64 channels - the input transform shared by twice the MFMAs - measured 51.3 against 50.1 ms)
-        static const bool ck8 = [] { const char* e = getenv("IFD_WINO_CK8"); return e != nullptr && e[0] == '1'; }();
-        if (HW >= 16 && ck8) return launch_wino<2, 2, false, 8>(a, n_img, s);
         if (HW >= 16) return launch_wino<2, 2>(a, n_img, s);
         return launch_wino<1, 4>(a, n_img, s);
     }
