@@ -486,6 +486,11 @@ __global__ __launch_bounds__(64 * TG * CG, TG * CG == 4 ? 2 : 1) void wino_kerne
         // (Steps of 8 input channels instead of 16 - 32 KB of LDS and 166 VGPRs per block, THREE blocks per CU, 8-byte operand
         // reads - was built and measured: 49.9 against 49.7 ms.  Occupancy is not what holds the kernel at 0.57 of the matrix
         // pipe: 2.4 other vector instructions per MFMA share that pipe, and the staging bytes per MFMA do not change.)
+        // (The operands swapped - D rows = output channels, D columns = tiles, so that a lane holds four CHANNELS of one tile, the
+        // epilogue is float4 arithmetic and a pixel's four channels leave as one 16-byte store instead of sixteen 4-byte stores per
+        // lane - was built and measured: 50.4 against 50.2 ms, nothing; the stores are not what the kernel waits for either.  One
+        // thing learnt on the way: `buffer_store_dwordx4 ... offen` with the region's base in the scalar offset operand wrote
+        // wrong data in that loop, the same operands with four 4-byte stores, or with the whole offset in the VGPR, did not.)
         // (Wave priorities for the MFMA phase - also a different one for each of the two waves that share a SIMD, so that the
         // two blocks of a CU alternate instead of falling into step - measured nothing: 50.07 against 50.16 ms.)
         if (chunk == 0) mfma_chunk(std::true_type{}); else mfma_chunk(std::false_type{});
