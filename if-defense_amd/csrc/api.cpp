@@ -90,6 +90,7 @@ struct ifd_ctx {
     ifd_config cfg{};
     std::vector<float> w;          // host copy, canonical order
     float* d_dec_img = nullptr;    // decoder parameter image (ifd_device.h layout)
+    float* d_dec_img_bf = nullptr; // ... and the bf16 piece image of the split-precision tiles (ifd_opt_params.precision 1 / 2)
     float* d_dec_img_opt = nullptr;// ... the persistent optimiser's copy: fc_0 / fc_1 / fc_out scaled by 2^RELU_K (ifd_device.h)
     float* d_w = nullptr;          // the whole canonical weight vector on the device (encoder kernels index it)
     EncPointOffsets eo{};
@@ -115,6 +116,10 @@ struct ifd_ctx {
     void* ws_mesh = nullptr;       // ONet-Mesh scratch (MISE arrays, triangle soup)
     unsigned long long mesh_points = 0, mesh_rounds = 0;   // grid points evaluated / MISE rounds of the last mesh call
     size_t ws_mesh_bytes = 0;
+    // read from the environment once, at creation (read_opt_env): bound of the cross-CU waits of split clouds, test hook
+    unsigned int coop_timeout_ticks = 3000000000u;
+    int test_drop_member = -1;
+    unsigned long long* d_status_out = nullptr;   // ifd_optimize_status: the status words as taken (atomic exchange) by status_take_kernel
     std::string err;
 };
 
@@ -191,17 +196,73 @@ std::vector<float> build_dec_image(const float* w, bool relu_scaled = false) {
     return img;
 }
 
+// The same parameters as bf16 pieces in MFMA operand order for the split-precision tiles (ifd_device.h, tile_bf.h).
+uint16_t bf16_rne(float f) {                        // round to nearest even, like v_cvt_pk_bf16_f32 (finite inputs)
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+std::vector<unsigned char> build_dec_image_bf(const float* w) {
+    const std::vector<float> f32img = build_dec_image(w);          // source of the folded biases (and of the layer order)
+    std::vector<unsigned char> img(BF_IMG_BYTES, 0);
+    uint16_t* h = reinterpret_cast<uint16_t*>(img.data());
+    for (int L = 0; L < 15; ++L)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = lane & 15, g = lane >> 4;
+                    const float x = f32img[DEC_OFF_W + L * W_LAYER + (16 * mt + m) * W_STRIDE + wperm(bf_chan(g, j))];
+                    const uint16_t h1 = bf16_rne(x);
+                    const float r1 = x - bf16_to_f32(h1);           // exact
+                    const uint16_t h2 = bf16_rne(r1);
+                    const float r2 = r1 - bf16_to_f32(h2);          // exact
+                    const uint16_t hs[3] = {h1, h2, bf16_rne(r2)};
+                    for (int sp = 0; sp < 3; ++sp)
+                        h[(size_t)(L * BF_LAYER_BYTES + sp * BF_PIECE_BYTES + (mt * 64 + lane) * BF_ENTRY_BYTES) / 2 + j] = hs[sp];
+                }
+    float* f = reinterpret_cast<float*>(img.data());
+    std::memcpy(f + BF_OFF_BIAS / 4, f32img.data() + DEC_OFF_BIAS, 15 * 32 * sizeof(float));
+    std::memcpy(f + BF_OFF_WP / 4, f32img.data() + DEC_OFF_WP, 32 * 4 * sizeof(float));
+    std::memcpy(f + BF_OFF_WOUT / 4, f32img.data() + DEC_OFF_WOUT, 32 * sizeof(float));
+    f[BF_OFF_BOUT / 4] = f32img[DEC_OFF_BOUT];
+    return img;
+}
+
 bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > LARGE_MAXK; }
 
-// Bound of the cross-CU waits of split clouds (knn_device.h coop_wait) and the test hook that provokes it.  Environment, not
-// ifd_opt_params: neither is part of the path's interface.  IFD_COOP_TIMEOUT_MS (default 2000: a wait normally lasts
-// microseconds, a whole launch under a second); IFD_TEST_COOP_DROP=<member>: that member of every split cloud never arrives.
-void opt_env_hooks(OptArgs& a) {
-    double ms = 2000.0;
+// Bound of the cross-CU waits of split clouds (knn_device.h coop_wait) and the test hook that provokes a time-out.  Environment,
+// not ifd_opt_params: neither is part of the path's interface.  Both are read ONCE, when the context is created (round-4 advisor:
+// no getenv on the path of every optimise call, and a stray variable must not be able to break a production context):
+//   IFD_COOP_TIMEOUT_MS   default 30000 - a wait normally lasts microseconds and a whole launch under a second, but the bound is
+//                         wall-clock time (s_memrealtime): a queue that is descheduled (another process time-slicing the GPU, a
+//                         profiler or debugger halt) keeps spending it;
+//   IFD_TEST_COOP_DROP=<member>  that member of every split cloud never arrives - honoured only together with
+//                         IFD_ENABLE_TEST_HOOKS=1 (tests/test_gpu_parity.py::test_split_cloud_wait_is_bounded_and_reported).
+struct OptEnv {
+    unsigned int coop_timeout_ticks;
+    int test_drop_member;
+};
+// the two sticky status words (overflow, time-out), taken and cleared atomically
+__global__ void status_take_kernel(unsigned long long* __restrict__ st, unsigned long long* __restrict__ out) {
+    if (threadIdx.x < 2) out[threadIdx.x] = atomicExch(st + threadIdx.x, 0ull);
+}
+OptEnv read_opt_env() {
+    OptEnv o;
+    double ms = 30000.0;
     if (const char* t = std::getenv("IFD_COOP_TIMEOUT_MS")) { const double x = std::atof(t); if (x > 0.0) ms = x; }
-    a.coop_timeout_ticks = (unsigned int)std::min(4.0e9, ms * 1.0e5);          // 100 MHz wall clock (s_memrealtime)
-    a.test_drop_member = -1;
-    if (const char* d = std::getenv("IFD_TEST_COOP_DROP")) a.test_drop_member = std::atoi(d);
+    o.coop_timeout_ticks = (unsigned int)std::min(4.0e9, ms * 1.0e5);          // 100 MHz wall clock (s_memrealtime)
+    o.test_drop_member = -1;
+    const char* en = std::getenv("IFD_ENABLE_TEST_HOOKS");
+    if (en != nullptr && en[0] == '1')
+        if (const char* d = std::getenv("IFD_TEST_COOP_DROP")) o.test_drop_member = std::atoi(d);
+    return o;
 }
 
 // Grow the context workspace.  Growing synchronises the device (hipFree), which only happens when a call
@@ -402,9 +463,16 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
             std::vector<float> img2 = build_dec_image(ctx->w.data(), true);
             e = hipMemcpy(ctx->d_dec_img_opt, img2.data(), DEC_FLOATS * sizeof(float), hipMemcpyHostToDevice);
         }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_dec_img_bf), BF_IMG_BYTES);
+        if (e == hipSuccess) {
+            std::vector<unsigned char> img3 = build_dec_image_bf(ctx->w.data());
+            e = hipMemcpy(ctx->d_dec_img_bf, img3.data(), BF_IMG_BYTES, hipMemcpyHostToDevice);
+        }
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
+    if (e == hipSuccess && !ctx->d_status_out) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status_out), 2 * sizeof(unsigned long long));
+    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_w), n_weights * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w, ctx->w.data(), n_weights * sizeof(float), hipMemcpyHostToDevice);
     {
@@ -445,10 +513,10 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
         g_create_error = std::string("ifd_create: ") + hipGetErrorString(e);
         if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
         if (ctx->d_dec_img_opt) (void)hipFree(ctx->d_dec_img_opt);
+        if (ctx->d_dec_img_bf) (void)hipFree(ctx->d_dec_img_bf);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_w) (void)hipFree(ctx->d_w);
         if (ctx->d_unet) (void)hipFree(ctx->d_unet);
-    if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
         if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
         delete ctx;
         return nullptr;
@@ -461,9 +529,11 @@ void ifd_destroy(ifd_ctx* ctx) {
     DeviceGuard guard(ctx);
     if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
     if (ctx->d_dec_img_opt) (void)hipFree(ctx->d_dec_img_opt);
+    if (ctx->d_dec_img_bf) (void)hipFree(ctx->d_dec_img_bf);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_status_out) (void)hipFree(ctx->d_status_out);
     if (ctx->d_w) (void)hipFree(ctx->d_w);
     if (ctx->d_unet) (void)hipFree(ctx->d_unet);
     if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
@@ -589,14 +659,19 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.dc = ctx->dc;
-    opt_env_hooks(a);
+    a.coop_timeout_ticks = ctx->coop_timeout_ticks;
+    a.test_drop_member = ctx->test_drop_member;
     if (prm->split != 0 && prm->split != 1 && prm->split != 2 && prm->split != 4)
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: split must be 0 (automatic), 1, 2 or 4");
+    if (prm->precision < 0 || prm->precision > 2)
+        return fail(ctx, IFD_ERR_ARG, "ifd_optimize: precision must be 0 (f32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
+    a.precision = K > MAXK ? 0 : prm->precision;      // (clouds beyond 1024 points: the launch-per-step path has the f32 tile only)
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (optimize.hip)
     hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : optimize_ws_bytes(B));
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
     e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters + STATUS_TIMEOUT_CUR, 0, sizeof(unsigned long long), static_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
     if (large) {
@@ -604,7 +679,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
                                   static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
     }
-    e = launch_optimize(ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
+    e = launch_optimize(a.precision != 0 ? ctx->d_dec_img_bf : ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
                         static_cast<const float*>(ctx->adam_tab), B, K, a, prm->split, ctx->n_cu, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch", e);
 }
@@ -628,13 +703,15 @@ int ifd_optimize_status(ifd_ctx* ctx, void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // read-and-reset in one atomic exchange per word: an event raised by a launch on another stream between a copy and a
+    // separate memset would have been cleared unreported (round-4 advisor)
     unsigned long long st[2] = {0, 0};
-    hipError_t e = hipMemcpyAsync(st, ctx->d_counters + STATUS_OVERFLOW, sizeof(st), hipMemcpyDeviceToHost, s);
+    hipLaunchKernelGGL(status_take_kernel, dim3(1), dim3(64), 0, s, ctx->d_counters + STATUS_OVERFLOW, ctx->d_status_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(st, ctx->d_status_out, sizeof(st), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize_status", e);
     if (st[0] == 0 && st[1] == 0) return IFD_OK;
-    e = hipMemsetAsync(ctx->d_counters + STATUS_OVERFLOW, 0, sizeof(st), s);       // reported once
-    if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize_status (reset)", e);
     char msg[256];
     if (st[1] != 0) {
         std::snprintf(msg, sizeof(msg), "split clouds: %llu cross-CU wait(s) gave up (a member workgroup never arrived: CUs masked or "
@@ -724,6 +801,8 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     upload(&ctx->d_onet_small, small);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
+    if (e == hipSuccess && !ctx->d_status_out) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status_out), 2 * sizeof(unsigned long long));
+    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; }
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e == hipSuccess) e = configure_onet_kernels();
@@ -795,7 +874,8 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     a.knn_scan_every_step = prm->knn_scan_every_step;
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
-    opt_env_hooks(a);
+    a.coop_timeout_ticks = ctx->coop_timeout_ticks;
+    a.test_drop_member = ctx->test_drop_member;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (onet.hip)
     hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : knn_list_bytes(B));
@@ -804,6 +884,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     float* ab = nullptr;
     e = onet_fold(ctx, c, B, s, &ab);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters + STATUS_TIMEOUT_CUR, 0, sizeof(unsigned long long), s);
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, s);
     if (e == hipSuccess && large)
         e = launch_onet_large_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud, ctx->ws,

@@ -40,6 +40,24 @@ constexpr int DEC_OFF_WOUT = DEC_OFF_WP + 32 * 4;    // [32]
 constexpr int DEC_OFF_BOUT = DEC_OFF_WOUT + 32;      // [1] (+3 pad)
 constexpr int DEC_FLOATS = DEC_OFF_BOUT + 4;         // 16964 floats = 67,856 B
 
+// ---- decoder parameter image of the split-precision tiles (tile_bf.h) --------------------------------------
+// The 15 layers as bf16 PIECES in the operand order of v_mfma_f32_16x16x32_bf16: w = w1 + w2 + w3 with w1 = bf16(w),
+// w2 = bf16(w - w1), w3 = bf16(w - w1 - w2) (round to nearest even; the three pieces carry the 24 mantissa bits exactly).
+//   [layer 15][piece 3][M-tile 2][lane 64][8 bf16]: lane (m = lane & 15, g = lane >> 4) of M-tile mt holds, for j = 0 ... 7,
+//   W[16 mt + m][bf_chan(g, j)] - one ds_read_b128 per A operand; element j of the B operand of lane group g is the accumulator
+//   register j of the layer before (channel bf_chan(g, j)): activations never leave registers, like in the f32 tile.
+// The transposed operand of the backward pass comes out of the SAME image through ds_read_b64_tr_b16 (tile_bf.h load_wfrag_bf).
+// Behind the layers, in f32: the biases [15][32] (fc_c's folded like in the f32 image), fc_p [32][4], fc_out [32], {fc_out's bias, 1 / B}.
+__host__ __device__ constexpr int bf_chan(int g, int j) { return 16 * (j >> 2) + 4 * g + (j & 3); }
+constexpr int BF_ENTRY_BYTES = 16;
+constexpr int BF_PIECE_BYTES = 2 * 64 * BF_ENTRY_BYTES;           // 2048: both M-tiles of one piece
+constexpr int BF_LAYER_BYTES = 3 * BF_PIECE_BYTES;               // 6144
+constexpr int BF_OFF_BIAS = 15 * BF_LAYER_BYTES;                 // 92,160: float [15][32]
+constexpr int BF_OFF_WP = BF_OFF_BIAS + 15 * 32 * 4;             // float [32][4]
+constexpr int BF_OFF_WOUT = BF_OFF_WP + 32 * 4 * 4;              // float [32]
+constexpr int BF_OFF_BOUT = BF_OFF_WOUT + 32 * 4;                // float [4]: fc_out's bias, 1 / B (written by the kernel), pad
+constexpr int BF_IMG_BYTES = BF_OFF_BOUT + 16;                   // 94,736 B
+
 // ---- packed ReLU of the optimiser tile (optimize.hip decoder_tile3) ---------------------------------------------------
 // gfx950 has no packed f32 max, but VOP3P float instructions take the clamp modifier: v_pk_mul_f32 a, 2^-K clamp gives
 // relu(a) * 2^-K for TWO values in one instruction (for a < 2^K; the clamp's upper end), half the vector instructions of a

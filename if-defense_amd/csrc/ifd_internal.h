@@ -12,6 +12,7 @@ struct OptArgs {
     DecConst dc;
     unsigned int coop_timeout_ticks;   // bound of a split cloud's cross-CU waits, in ticks of the 100 MHz wall clock (knn_device.h coop_wait)
     int test_drop_member;              // test hook (env IFD_TEST_COOP_DROP): this member of every split cloud never arrives; -1 = off
+    int precision;                     // ifd_opt_params.precision: 0 f32 MFMA tiles, 1 bf16x6, 2 bf16x3 (tile_bf.h); the caller passes the matching image
 };
 
 // The context's device counter buffer (api.cpp d_counters, unsigned long long): IFD_N_COUNTERS public diagnostics of the last
@@ -21,7 +22,12 @@ struct OptArgs {
 constexpr int DEV_COUNTERS = 16 + 8 * 32;
 constexpr int STATUS_OVERFLOW = DEV_COUNTERS;
 constexpr int STATUS_TIMEOUT = DEV_COUNTERS + 1;
-constexpr int TRACE2_BASE = DEV_COUNTERS + 2;        // -DIFD_TRACE2 builds: [8 waves][128] stamps inside one decoder tile per wave
+// ... and the time-out word of the CURRENT optimise call: cleared by every ifd_optimize / ifd_onet_optimize in front of its launches.
+// A waiter that gives up raises this word and the sticky one; the other waiters fall out on THIS word only (round-4 advisor: when
+// they looked at the sticky word, one time-out made the first wait of every later launch on the context fail too, until the host
+// had called ifd_optimize_status).
+constexpr int STATUS_TIMEOUT_CUR = DEV_COUNTERS + 2;
+constexpr int TRACE2_BASE = DEV_COUNTERS + 3;        // -DIFD_TRACE2 builds: [8 waves][128] stamps inside one decoder tile per wave
 constexpr int DEV_COUNTERS_TOTAL = TRACE2_BASE + 8 * 128;
 
 // offsets (floats) of the point-net tensors inside the canonical weight vector (include/ifd.h order)

@@ -644,17 +644,20 @@ __device__ __forceinline__ void coop_arrive(unsigned int* ctr) {
 // Wait until `ctr` reaches `target` (call it wave-uniformly).  The wait is BOUNDED: members of a split cloud are co-resident
 // by construction (one workgroup per CU, launch_optimize), but a CU mask, another process holding CUs with its own split
 // launch, or a member that died would otherwise leave the survivors spinning for ever (return a status,
-// never hang / exit).  After `limit` ticks of the 100 MHz wall clock (s_memrealtime) the waiter raises the launch's sticky
-// timeout word; every waiter that sees the word falls out at once, the kernel leaves its step loop at the next workgroup
-// barrier (results are garbage), and ifd_optimize_status() returns IFD_ERR_TIMEOUT.  Returns false if it gave up.
+// never hang / exit).  After `limit` ticks of the 100 MHz wall clock (s_memrealtime: time the queue spends descheduled counts
+// too, hence a generous default of 30 s - IFD_COOP_TIMEOUT_MS) the waiter raises the context's sticky time-out word and the
+// time-out word of the current call (ifd_internal.h); every waiter that sees the CURRENT call's word falls out at once, the
+// kernel leaves its step loop at the next workgroup barrier (results are garbage), and ifd_optimize_status() returns
+// IFD_ERR_TIMEOUT.  Returns false if it gave up.
 __device__ __forceinline__ bool coop_wait(unsigned int* ctr, unsigned int target, unsigned long long* status, unsigned int limit) {
     bool ok = true;
     if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned int it = 0;; ++it) {
             if ((it & 31u) == 0u && status != nullptr) {
-                if (__hip_atomic_load(status + STATUS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { ok = false; break; }
+                if (__hip_atomic_load(status + STATUS_TIMEOUT_CUR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { ok = false; break; }
                 if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) {
+                    __hip_atomic_fetch_add(status + STATUS_TIMEOUT_CUR, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(status + STATUS_TIMEOUT, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = false;
                     break;

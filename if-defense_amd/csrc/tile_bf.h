@@ -1,0 +1,468 @@
+// The optimiser's decoder tile on the bf16 matrix core with f32-exact operand splits ("split precision", SURVEY 8f N4;
+// ConvONet/src/conv_onet/models/decoder.py:83-93, layers.py:39-48).  Included by optimize_kernel.h inside namespace ifd,
+// behind decoder_tile3 (whose geometry / mask / accumulator helpers it shares).
+//
+// Why: an f32 MFMA runs on the vector ALU's multipliers - it excludes every vector instruction on its SIMD
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r04_pmc_fifo.txt), so the f32 tile's time is the SUM of its matrix and vector
+// cycles and a bubble-free f32 kernel ends at 0.74 of the f32 peak.  A bf16 MFMA runs on the matrix core proper,
+// 16x faster, beside the vector pipe.  Every f32 value is the exact sum of three bf16 pieces (8 + 8 + 8 mantissa bits, round
+// to nearest: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)), so with both operands split
+//     w x = sum_ij w_i x_j;   PREC 1 ("bf16x6"): w1 x1 + w1 x2 + w2 x1 + w2 x2 + w1 x3 + w3 x1   (dropped: <= 2^-26 |w x|)
+//                             PREC 2 ("bf16x3"): w1 x1 + w1 x2 + w2 x1                           (dropped: <= 2^-17 |w x|)
+// every product of pieces is exact in the MFMA's f32 accumulation, one instruction sums 32 of them with ONE rounding (the f32
+// MFMA chain rounds 32 times), and the six-term form measures MORE accurate than the f32 MFMA chain against float64
+// (profiles/r05_bf16x6_probe.txt: max error 3.9e-7 against 9.1e-7 on one layer) at half its cycles.
+//
+// The splits are made on the matrix pipe too: r = relu(x) - x1 is ONE MFMA with A = minus a selection matrix, B = the x1 piece
+// that has just been packed, C = relu(x) (exact: x1 is within 2^-9 of C and the other products are exact zeros); the vector
+// pipe only converts (v_cvt_pk_bf16_f32: 12 per 8 values and layer).  Per layer and 16-point sub-tile: 12 + 4 MFMAs of
+// 16x16x32 (16 cycles each) against 16 of 16x16x4 f32 (32 cycles each) - and the vector instructions run beside them.
+//
+// Operand mapping (v_mfma_f32_16x16x32_bf16: M = output channel, N = point, K = input channel): lane (n = lane & 15, g = lane >> 4)
+// holds A[m = n][k = 8 g + j] and B[k = 8 g + j][n], j = 0 ... 7, and D[4 g + r][n].  With two M-tiles a lane holds the channels
+// bf_chan(g, e) = 16 (e >> 2) + 4 g + (e & 3), e = 4 mt + r, of its point - the f32 tile's layout - and k-slot 8 g + j of the next
+// layer IS accumulator register j: activations stay in registers, the weight image is permuted instead (ifd_device.h).
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct Pieces {
+    bf16x8 p[3];        // x1, x2, x3 of the lane's eight values: the B operands of the next layer
+};
+struct SelMat {
+    bf16x8 m[2];        // per M-tile: -1 at the k-slot that holds the M-tile's row channel, 0 elsewhere
+};
+struct WFragBF {
+    bf16x8 a[3][2];     // [piece][M-tile]
+};
+
+// lane (m, g), M-tile mt: element j is -1 iff bf_chan(g, j) == 16 mt + m, i.e. j = 4 mt + (m - 4 g) with 0 <= m - 4 g < 4
+__device__ __forceinline__ SelMat make_selmat(int lane) {
+    const int d = (lane & 15) - 4 * (lane >> 4);
+    const unsigned int val = (d & ~3) == 0 ? (0xBF80u << (16 * (d & 1))) : 0u;       // bf16(-1.0) in the element's half of its dword
+    const unsigned int v0 = (d >> 1) == 0 ? val : 0u, v1 = (d >> 1) == 1 ? val : 0u;
+    typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+    SelMat s;
+    s.m[0] = __builtin_bit_cast(bf16x8, u32x4s{v0, v1, 0u, 0u});
+    s.m[1] = __builtin_bit_cast(bf16x8, u32x4s{0u, 0u, v0, v1});
+    return s;
+}
+
+__device__ __forceinline__ bf16x8 cvt8_bf(const f32x8& v) {        // four v_cvt_pk_bf16_f32 (round to nearest even)
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+    return o;
+}
+__device__ __forceinline__ f32x4 mfma_bf(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// x -> x1, x2 (, x3); the residuals on the matrix pipe.  PREC 2 stops at two pieces.
+template <int PREC>
+__device__ __forceinline__ void split_bf(const f32x8& x, const SelMat& sel, Pieces& P) {
+    P.p[0] = cvt8_bf(x);
+    f32x4 c0 = {x[0], x[1], x[2], x[3]}, c1 = {x[4], x[5], x[6], x[7]};
+    c0 = mfma_bf(sel.m[0], P.p[0], c0);
+    c1 = mfma_bf(sel.m[1], P.p[0], c1);
+    P.p[1] = cvt8_bf(f32x8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]});
+    if (PREC == 1) {
+        c0 = mfma_bf(sel.m[0], P.p[1], c0);
+        c1 = mfma_bf(sel.m[1], P.p[1], c1);
+        P.p[2] = cvt8_bf(f32x8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]});
+    } else {
+        P.p[2] = P.p[1];
+    }
+}
+
+// acc += W x from the pieces, small terms first; the two M-tiles are independent accumulator chains
+template <int PREC>
+__device__ __forceinline__ void dense_bf(const WFragBF& A, const Pieces& P, Acc2& acc) {
+    if (PREC == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[2][mt], P.p[0], acc.t[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[0][mt], P.p[2], acc.t[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[1][mt], P.p[1], acc.t[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[1][mt], P.p[0], acc.t[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[0][mt], P.p[1], acc.t[mt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[0][mt], P.p[0], acc.t[mt]);
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+// (scalar: no packed-f32 instructions in this tile, see decoder_tile3_bf)
+__device__ __forceinline__ Acc2 acc_add_s(const Acc2& a, const Acc2& b) {
+    Acc2 r;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.t[mt][j] = a.t[mt][j] + b.t[mt][j];
+    return r;
+}
+__device__ __forceinline__ void add8_s(f32x8& d, const f32x8& t) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] += t[r];
+}
+
+// A operands of one layer.  Forward: the entry of (piece, M-tile, lane) as it lies.  Transposed (backward: A = W^T, rows = input
+// channel 16 mt + m, k-slot 8 g + j = output channel bf_chan(g, j)): ds_read_b64_tr_b16 hands lane L of a 16-lane block, for
+// j' = 0 ... 3, element (L & 3) of the 8 bytes that lane 4 j' + (L >> 2) of the block addressed (profiles/r05_ds_read_tr16_probe.txt).
+// So block g's lane R = 4 j' + mh addresses the four input channels 16 mt + 4 mh + (0 ... 3) of output row 16 jh + 4 g + j' - the
+// entry (M-tile jh, lane (4 g + j', mh)) of the forward image at element 4 mt - and lane m receives W[16 jh + 4 g + j'][16 mt + m],
+// j' = 0 ... 3: the four elements 4 jh + j' of its transposed operand.  Two reads (jh = 0, 1) per operand.
+template <bool TRANSPOSED, int PREC>
+__device__ __forceinline__ WFragBF load_wfrag_bf(const lds_u8* __restrict__ Wb, int layer, int lane_off, int lane_off_t) {
+    WFragBF f;
+    constexpr int NP = PREC == 1 ? 3 : 2;
+    const lds_u8* base = Wb + layer * BF_LAYER_BYTES;
+#pragma unroll
+    for (int sp = 0; sp < NP; ++sp)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (!TRANSPOSED) {
+                f.a[sp][mt] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(base + sp * BF_PIECE_BYTES + mt * 1024 + lane_off);
+            } else {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(base + sp * BF_PIECE_BYTES + 0 * 1024 + lane_off_t + 8 * mt));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(base + sp * BF_PIECE_BYTES + 1 * 1024 + lane_off_t + 8 * mt));
+                f.a[sp][mt] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            }
+        }
+    if (PREC != 1) { f.a[2][0] = f.a[1][0]; f.a[2][1] = f.a[1][1]; }
+    return f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two 16-point sub-tiles per wave, software-pipelined like decoder_tile3: the 12 MFMAs of one sub-tile's layer beside the
+// epilogue (bias, ReLU, mask, split: ~27 vector instructions + 4 MFMAs) of the other's.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE, int PREC>
+__device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, __amdgpu_buffer_rsrc_t planes,
+                                                 const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, int lane,
+                                                 const DecConst dc, float thr, bool want_loss, float (&bce)[2], float (&dx)[2][3]) {
+    const lds_u8* Wb = (const lds_u8*)Wg;
+    const int n = lane & 15, q = lane >> 4;
+    int lane_off = lane * BF_ENTRY_BYTES;
+    int lane_off_t = ((lane & 3) * 16 + 4 * q + ((lane >> 2) & 3)) * BF_ENTRY_BYTES;
+    int q4 = 4 * q;
+    asm volatile("" : "+v"(lane_off), "+v"(lane_off_t), "+v"(q4));
+    constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)
+    const float ksc = ((0.5f * (float)(RES - 1)) * 2.f) / dc.sdiv;
+    SubGeo geo[2];
+    sub_geometry(geo[0], ppa, ksc);
+    sub_geometry(geo[1], ppb, ksc);
+    const float* Wf = reinterpret_cast<const float*>(Wg);
+    int boff = BF_OFF_BIAS / 4 + q4;
+    asm volatile("" : "+v"(boff));
+    const float* Bq = Wf + boff;
+    auto bias = [&](int layer) {
+        Acc2 b;
+        b.t[0] = *reinterpret_cast<const f32x4*>(Bq + layer * 32);
+        b.t[1] = *reinterpret_cast<const f32x4*>(Bq + layer * 32 + 16);
+        return b;
+    };
+
+    // ---- gather + forward bilinear sample (decoder_tile3's, unchanged) ------------------------------------------------
+    f32x8 c[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
+    const int q16 = 16 * q;
+    auto load_taps = [&](int P, f32x4 (&tap)[2][4][2], bool opaque) {
+        const int a0 = AX0[P], a1 = AX1[P];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int off = (geo[t].cell[a1] * RES + geo[t].cell[a0]) * (CH * 4) + (P * PLANE_FLOATS * 4 + q16);
+            if (opaque) asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const u32x4v t0 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + 64 * mt, 0, 0);
+                const u32x4v t1 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + CH * 4 + 64 * mt, 0, 0);
+                const u32x4v t2 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + RES * CH * 4 + 64 * mt, 0, 0);
+                const u32x4v t3 = __builtin_amdgcn_raw_buffer_load_b128(planes, off + RES * CH * 4 + CH * 4 + 64 * mt, 0, 0);
+                tap[t][0][mt] = __builtin_bit_cast(f32x4, t0);
+                tap[t][1][mt] = __builtin_bit_cast(f32x4, t1);
+                tap[t][2][mt] = __builtin_bit_cast(f32x4, t2);
+                tap[t][3][mt] = __builtin_bit_cast(f32x4, t3);
+            }
+        }
+    };
+    // NO packed-f32 instruction anywhere in this tile (nor, through -fno-slp-vectorize, in the rest of this kernel): beside a wave
+    // that streams bf16 MFMAs, a v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 whose consumer does not follow back to back
+    // occasionally delivers a wrong result on gfx950 (scripts/pk_mfma_coexec.hip, profiles/r05_pk_mfma_coexec.txt: 0 wrong of 5e9
+    // beside an idle or an f32-MFMA partner, 16 ... 300 of 5e9 beside a bf16-MFMA partner - ~1 % of a launch's sub-tiles here).
+    // decoder_tile3's packed sampling is therefore spelled out value by value: same operations, same order, same roundings.
+    auto sample_fwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
+        const int a0 = AX0[P], a1 = AX1[P];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SubGeo& g = geo[t];
+            const float wnw = g.w0[a0] * g.w0[a1], wne = g.w1[a0] * g.w0[a1], wsw = g.w0[a0] * g.w1[a1],
+                        wse = g.w1[a0] * g.w1[a1];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s1 = tap[t][0][mt][j] * wnw;
+                    s1 = __builtin_fmaf(tap[t][1][mt][j], wne, s1);
+                    s1 = __builtin_fmaf(tap[t][2][mt][j], wsw, s1);
+                    s1 = __builtin_fmaf(tap[t][3][mt][j], wse, s1);
+                    c[t][4 * mt + j] = P == 0 ? s1 : c[t][4 * mt + j] + s1;
+                }
+        }
+    };
+    {
+        f32x4 tap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
+        load_taps(0, tap0, false);
+        load_taps(1, tap1, false);
+        load_taps(2, tap2, false);
+        __builtin_amdgcn_sched_barrier(0);
+        // one explicit wait per plane (s_waitcnt vmcnt(32) / (16) / (0): the planes' 16 loads each, oldest first) instead of hipcc's
+        // load-by-load waits inside the multiply-add chains
+        __builtin_amdgcn_s_waitcnt(0x8F70);
+        __builtin_amdgcn_sched_barrier(0);
+        sample_fwd(0, tap0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x4F70);
+        __builtin_amdgcn_sched_barrier(0);
+        sample_fwd(1, tap1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+        sample_fwd(2, tap2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    const SelMat sel = make_selmat(lane);
+    // ---- fc_p on the f32 matrix instruction (K = 4: x, y, z, 1 - two MFMAs per sub-tile, as in decoder_tile3) --------------
+    Acc2 net[2];
+    {
+        const float ap0 = Wf[BF_OFF_WP / 4 + n * 4 + q], ap1 = Wf[BF_OFF_WP / 4 + (16 + n) * 4 + q];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float xq = t ? xqb : xqa;
+            net[t].t[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap0, xq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            net[t].t[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap1, xq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+    WFragBF A = load_wfrag_bf<false, PREC>(Wb, 0, lane_off, lane_off_t);
+    Pieces PC[2];                                  // the sampled features c: the input of all five fc_c
+    split_bf<PREC>(c[0], sel, PC[0]);
+    split_bf<PREC>(c[1], sel, PC[1]);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- forward MLP -----------------------------------------------------------------------------------------------
+    Mask8 mask_a[2][NBLK], mask_h[2][NBLK];
+    f32x8 wout;
+    float bout = 0.f, ilb = 0.f;
+    int c31 = 31;
+    asm volatile("" : "+v"(c31));
+    const unsigned long long sc2 = 0ull;           // (packed-ReLU scale of decoder_tile3: RELU_K = 0 here)
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        // fc_c: a = n + fc_c(c)   (bias folded into n)
+        Acc2 a0 = net[0], a1 = net[1];
+        dense_bf<PREC>(A, PC[0], a0);                                          // R1
+        __builtin_amdgcn_sched_barrier(0);
+        const WFragBF A0 = load_wfrag_bf<false, PREC>(Wb, 3 * i + 1, lane_off, lane_off_t);   // R2: prefetch fc_0
+        const Acc2 B0 = bias(3 * i + 1);
+        dense_bf<PREC>(A, PC[1], a1);
+        Pieces PA0, PA1, PH0, PH1;
+        {
+            f32x8 ra;
+            relu_and_mask(flat(a0), c31, sc2, ra, mask_a[0][i]);
+            split_bf<PREC>(ra, sel, PA0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Acc2 h0 = B0;                                                          // R3
+        dense_bf<PREC>(A0, PA0, h0);
+        {
+            f32x8 ra;
+            relu_and_mask(flat(a1), c31, sc2, ra, mask_a[1][i]);
+            split_bf<PREC>(ra, sel, PA1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const WFragBF A1 = load_wfrag_bf<false, PREC>(Wb, 3 * i + 2, lane_off, lane_off_t);   // R4: prefetch fc_1
+        const Acc2 B1 = bias(3 * i + 2);
+        Acc2 h1 = B0;
+        dense_bf<PREC>(A0, PA1, h1);
+        {
+            f32x8 rh;
+            relu_and_mask(flat(h0), c31, sc2, rh, mask_h[0][i]);
+            split_bf<PREC>(rh, sel, PH0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Acc2 o0 = acc_add_s(B1, a0);                                             // R5
+        dense_bf<PREC>(A1, PH0, o0);
+        {
+            f32x8 rh;
+            relu_and_mask(flat(h1), c31, sc2, rh, mask_h[1][i]);
+            split_bf<PREC>(rh, sel, PH1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < NBLK) {                                                    // R6: prefetch the next fc_c / the first fc_1^T
+            A = load_wfrag_bf<false, PREC>(Wb, 3 * i + 3, lane_off, lane_off_t);
+        } else {
+            A = load_wfrag_bf<true, PREC>(Wb, 3 * i + 2, lane_off, lane_off_t);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(Wf + BF_OFF_WOUT / 4 + q4);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(Wf + BF_OFF_WOUT / 4 + 16 + q4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { wout[r] = t0[r]; wout[4 + r] = t1[r]; }
+            const f32x2 bo = *reinterpret_cast<const f32x2*>(Wf + BF_OFF_BOUT / 4);
+            bout = bo.x;
+            ilb = bo.y;
+        }
+        Acc2 o1 = acc_add_s(B1, a1);
+        dense_bf<PREC>(A1, PH1, o1);
+        net[0] = o0;
+        net[1] = o1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- logit, loss derivative, seed of the backward pass (decoder_tile3's) ---------------------------------------------
+    f32x8 dn[2];
+    Pieces PD[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x8 nf = flat(net[t]);
+        f32x8 rn;
+        Mask8 mask_n;
+        relu_and_mask(nf, c31, sc2, rn, mask_n);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part = fmaf(wout[r], rn[r], part);
+        part = add_lane_xor32(add_lane_xor16(part));
+        const float logit = part + bout;
+        float dl;
+        if (MODE == MODE_OPT) {
+            const float e = expf(-fabsf(logit));
+            const float rc = __builtin_amdgcn_rcpf(1.f + e);
+            const float sig = logit >= 0.f ? rc : e * rc;
+            dl = (sig - thr) * ilb;
+            bce[t] = want_loss ? fmaxf(logit, 0.f) - thr * logit + log1pf(e) : 0.f;
+        } else {
+            bce[t] = logit;
+            dl = 1.f;
+        }
+        f32x8 dw;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dw[r] = dl * wout[r];
+        dn[t] = masked(dw, mask_n);
+        split_bf<PREC>(dn[t], sel, PD[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- backward (A holds fc_1[4]^T) --------------------------------------------------------------------------------------
+    Acc2 dcc[2] = {acc_zero(), acc_zero()};
+#pragma unroll
+    for (int i = NBLK - 1; i >= 0; --i) {
+        Acc2 z0 = acc_zero();                                                  // R1: fc_1^T dn (sub-tile 0)
+        dense_bf<PREC>(A, PD[0], z0);
+        __builtin_amdgcn_sched_barrier(0);
+        const WFragBF A0 = load_wfrag_bf<true, PREC>(Wb, 3 * i + 1, lane_off, lane_off_t);    // R2: prefetch fc_0^T
+        Acc2 z1 = acc_zero();
+        dense_bf<PREC>(A, PD[1], z1);
+        Pieces PH0, PH1;
+        split_bf<PREC>(masked(z0, mask_h[0][i]), sel, PH0);
+        __builtin_amdgcn_sched_barrier(0);
+        Acc2 y0 = acc_zero();                                                  // R3: fc_0^T dh (sub-tile 0)
+        dense_bf<PREC>(A0, PH0, y0);
+        split_bf<PREC>(masked(z1, mask_h[1][i]), sel, PH1);
+        __builtin_amdgcn_sched_barrier(0);
+        const WFragBF Ac = load_wfrag_bf<true, PREC>(Wb, 3 * i, lane_off, lane_off_t);        // R4: prefetch fc_c^T
+        Acc2 y1 = acc_zero();
+        dense_bf<PREC>(A0, PH1, y1);
+        {
+            const f32x8 t = masked(y0, mask_a[0][i]);
+            add8_s(dn[0], t);                                                 // delta a_i
+            split_bf<PREC>(dn[0], sel, PD[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dense_bf<PREC>(Ac, PD[0], dcc[0]);                                     // R5: dc += fc_c^T da (sub-tile 0)
+        {
+            const f32x8 t = masked(y1, mask_a[1][i]);
+            add8_s(dn[1], t);
+            split_bf<PREC>(dn[1], sel, PD[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i > 0) A = load_wfrag_bf<true, PREC>(Wb, 3 * i - 1, lane_off, lane_off_t);        // R6: prefetch fc_1[i-1]^T
+        dense_bf<PREC>(Ac, PD[1], dcc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- fc_p backward and d c / d u through the re-gathered taps (decoder_tile3's) -----------------------------------------
+    float g[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(Wf + BF_OFF_WP / 4 + (16 * mt + j) * 4 + q4 * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float d = dn[t][4 * mt + j];
+                g[t][0] = fmaf(wp.x, d, g[t][0]); g[t][1] = fmaf(wp.y, d, g[t][1]); g[t][2] = fmaf(wp.z, d, g[t][2]);
+            }
+        }
+    f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
+    auto sample_bwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
+        const int a0 = AX0[P], a1 = AX1[P];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SubGeo& gg = geo[t];
+            // even / odd channel partial sums like decoder_tile3's packed form (pairs added at the end): the same roundings
+            float pnw[2] = {0.f, 0.f}, pne[2] = {0.f, 0.f}, psw[2] = {0.f, 0.f}, pse[2] = {0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = dcf[t][4 * mt + j];
+                    pnw[j & 1] = __builtin_fmaf(tap[t][0][mt][j], d, pnw[j & 1]);
+                    pne[j & 1] = __builtin_fmaf(tap[t][1][mt][j], d, pne[j & 1]);
+                    psw[j & 1] = __builtin_fmaf(tap[t][2][mt][j], d, psw[j & 1]);
+                    pse[j & 1] = __builtin_fmaf(tap[t][3][mt][j], d, pse[j & 1]);
+                }
+            float pgx[2], pgy[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                pgx[h] = __builtin_fmaf(pse[h] - psw[h], gg.w1[a1], (pne[h] - pnw[h]) * gg.w0[a1]);
+                pgy[h] = __builtin_fmaf(pse[h] - pne[h], gg.w1[a0], (psw[h] - pnw[h]) * gg.w0[a0]);
+            }
+            const float gix = pgx[0] + pgx[1], giy = pgy[0] + pgy[1];
+            g[t][a0] = fmaf(gg.lk[a0], gix, g[t][a0]);
+            g[t][a1] = fmaf(gg.lk[a1], giy, g[t][a1]);
+        }
+    };
+    {
+        f32x4 btap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
+        load_taps(0, btap0, true);
+        load_taps(1, tap1, true);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x4F70);      // (whole planes, as in the forward gather)
+        __builtin_amdgcn_sched_barrier(0);
+        sample_bwd(0, btap0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_taps(2, tap2, true);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x4F70);
+        __builtin_amdgcn_sched_barrier(0);
+        sample_bwd(1, tap1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+        sample_bwd(2, tap2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dx[t][a] = add_lane_xor32(add_lane_xor16(g[t][a]));
+}

@@ -133,7 +133,8 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
             if ev is not None:
                 main.wait_event(ev)
             h["out"][lo:hi] = r.optimize_points(init, planes, rep_weight=args.rep_weight, iterations=args.iterations,
-                                                lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing)
+                                                lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing,
+                                                **({"check": False} if on_gpu and hasattr(r, "check_status") else {}))
         ready = launch_prepare(nxt_u) if nxt_u is not None else None               # rides on the optimiser's tail
         if last:
             if on_gpu and hasattr(r, "check_status") and os.environ.get("IFD_STATUS_CHECK", "1") != "0":

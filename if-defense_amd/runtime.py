@@ -20,6 +20,18 @@ PLANE_ORDER = ("xz", "xy", "yz")
 # measurement hook: IFD_SPLIT=1|2|4 overrides the automatic choice of ifd_opt_params.split (results do not depend on it)
 import os as _os
 _ENV_SPLIT = int(_os.environ.get("IFD_SPLIT", "0"))
+# ifd_opt_params.precision by name; IFD_PRECISION=f32|bf16x6|bf16x3 is the default where a caller passes None (measurement hook)
+PRECISIONS = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
+
+
+def precision_code(precision) -> int:
+    if precision is None:
+        precision = _os.environ.get("IFD_PRECISION", "f32")
+    if isinstance(precision, str):
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+        return PRECISIONS[precision]
+    return int(precision)
 
 
 class IfdError(RuntimeError):
@@ -199,16 +211,21 @@ class Restorer:
                         state: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
                         return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
                         knn_scan_every_step: bool = False, printing: bool = False, split: int = 0,
-                        planes_shared: bool = False, rep_radius: float = 0.07, rep_h: float = 0.03, check: bool = False):
+                        planes_shared: bool = False, rep_radius: float = 0.07, rep_h: float = 0.03, check: bool = True,
+                        precision=None):
         """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
         is given.  ``loss_batch`` is the reference batch size whose 1/B factor scales both losses
         (default: the number of clouds passed in); an int, or an int32 tensor [B] with one value per cloud.  ``state=(m, v, t0)`` resumes / teacher-forces.
         ``split``: CUs per cloud (ifd_opt_params.split: 0 automatic, 1 / 2 / 4 forced; same results).
+        ``precision``: arithmetic of the decoder's dense layers (ifd_opt_params.precision): "f32" / 0 (default), "bf16x6" / 1
+        (f32-equivalent on the bf16 matrix core), "bf16x3" / 2 (reduced); None takes the environment's IFD_PRECISION (default f32).
         ``rep_radius`` / ``rep_h``: RepulsionLoss(radius, h) (defense/repulsion_loss.py:9-10; the reference never changes them).
-        ``check``: synchronise and raise IfdError on a device-side failure (``check_status``); the drivers of pipeline.py
-        check once per file instead, where the result is consumed.
+        ``check`` (default on): synchronise and raise IfdError on a device-side failure (``check_status``: a split cloud's
+        bounded wait that gave up, repulsion sums near their range) - a caller that gets points back can trust them.  The drivers
+        of pipeline.py pass ``check=False`` and check once per file instead, where the result is consumed (no synchronisation
+        inside the streamed passes).
         Returns the points as a torch tensor on the device ([B,K,3]); the reference's ``.cpu().numpy()``
         is left to the caller.
         """
@@ -234,7 +251,8 @@ class Restorer:
             loss_batch = B
         prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
                            float(lr), float(rep_weight), self.threshold, float(rep_radius), float(rep_h), 1e-12,
-                           int(bool(knn_scan_every_step)), int(split or _ENV_SPLIT), int(bool(planes_shared)))
+                           int(bool(knn_scan_every_step)), int(split or _ENV_SPLIT), int(bool(planes_shared)),
+                           precision_code(precision))
         with torch.cuda.device(self.device):
             self._check(self._fn_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
                                               self._ptr(lb_arr), self._ptr(m), self._ptr(v), self._ptr(loss),

@@ -50,7 +50,8 @@ extern "C" {
 #endif
 
 /* 2: ifd_opt_params grew (split, planes_shared - round 3), ifd_optimize_status and the two status codes below were added */
-#define IFD_ABI_VERSION 2
+/* 3: ifd_opt_params.precision (round 5) */
+#define IFD_ABI_VERSION 3
 
 enum {
     IFD_OK = 0,
@@ -192,6 +193,13 @@ typedef struct ifd_opt_params {
                              split launches on one GPU at the same time (set 1 there). */
     int32_t planes_shared;/* measurement only: != 0 makes every cloud read the planes of cloud 0 (the tap gathers then hit in
                              L2: scripts/ab_planes.py prices the gather traffic this way) */
+    int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers in the persistent kernel (K <= 1024):
+                             0 = f32 MFMA (v_mfma_f32_16x16x4_f32: bit-equal to an fmaf chain) - the default;
+                             1 = "bf16x6": both operands split exactly into three bf16 pieces, six piece products on the bf16
+                                 matrix core, f32 accumulation - f32-equivalent (dropped terms <= 2^-26 of a product, one
+                                 rounding per 32-term sum: measured closer to float64 than the f32 MFMA chain);
+                             2 = "bf16x3": two pieces, three products - reduced precision, 2^-17 of a product.
+                             Everything else (sampling, fc_p, fc_out, loss, kNN, repulsion, Adam) is f32 in every mode. */
 } ifd_opt_params;
 
 /* optimize_points(opt_points, z, c, rep_weight, iterations) (ConvONet/opt_defense.py:182-239).
@@ -227,7 +235,8 @@ int ifd_get_counters(ifd_ctx* ctx, uint64_t* out_host, int n);
  * where the results are consumed), resets the words, returns
  *   IFD_OK
  *   IFD_ERR_TIMEOUT   a member workgroup of a split cloud (ifd_opt_params.split != 1) did not arrive within the bound of the
- *                     cross-CU waits (2 s; environment IFD_COOP_TIMEOUT_MS) - CUs masked or held by another process's split
+ *                     cross-CU waits (30 s of wall-clock time; environment IFD_COOP_TIMEOUT_MS, read when the context is
+ *                     created) - CUs masked or held by another process's split
  *                     launch.  Every waiter falls out, the launch ends early, its output is invalid.
  *   IFD_ERR_OVERFLOW  the repulsion gradient of some point summed to |x| >= 128 in a step: the 32-bit fixed-point accumulators
  *                     (2^-23 units, wrap at 256) are within a factor two of wrapping; with the reference's radius / h the sum

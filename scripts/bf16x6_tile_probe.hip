@@ -209,6 +209,17 @@ static void run(const char* name, const void* dimg, size_t img_bytes, const floa
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     }
+    {   // run-to-run determinism of the chained layers
+        std::vector<float> Y1((size_t)P * 32), Y2((size_t)P * 32);
+        hipMemcpy(Y1.data(), dy, Y1.size() * 4, hipMemcpyDeviceToHost);
+        size_t nd = 0;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipLaunchKernelGGL(tile_probe<MODE>, dim3(blocks), dim3(512), shm, 0, dimg, dx, dy, dcyc, iters, 0);
+            hipMemcpy(Y2.data(), dy, Y2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < Y1.size(); ++i) nd += memcmp(&Y1[i], &Y2[i], 4) != 0;
+        }
+        printf("%-28s values that differ between repeated launches (5 repeats, %zu values each): %zu\n", name, Y1.size(), nd);
+    }
     unsigned long long cyc = 0;
     hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost);
     const double per = (double)cyc / (iters * NL * 2);        // per layer and sub-tile, one wave (two waves share the SIMD)

@@ -51,7 +51,7 @@ def test_exports_are_c_abi():
 
 def test_abi_version_and_weight_count(lib):
     from ifdefense_amd import weights
-    assert lib.ifd_abi_version() == 2
+    assert lib.ifd_abi_version() == 3
     n = sum(int(np.prod(s)) for _, s in weights.canonical_keys())
     assert n == 16001 + 27232 + 1934976 == lib.ifd_weight_count()
 
@@ -197,23 +197,26 @@ def _gfx950_code_objects(path):
         i += 24
 
 
-def test_split_cloud_arrivals_are_preceded_by_a_vmcnt0_wait(lib, tmp_path):
-    """Round-3 advisor finding: a member of a split cloud must drain its stores / atomics to the exchange block
-    (`s_waitcnt vmcnt(0)`, knn_device.h coop_publish) before it bumps an arrival counter - the workgroup-scope release
-    fence alone emits no vmcnt wait on gfx950.  Checked in the shipped ISA: in optimize_kernel<8, 2> and <8, 4> the nearest
-    preceding memory-write-or-wait of every arrival atomic (a 32-bit global_atomic_add through an SGPR base) is the wait."""
-    import ifdefense_amd as I
+def _disassemblies(lib_path, tmp_path):
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not in this image")
-    found = {}
-    for k, co in enumerate(_gfx950_code_objects(I.LIB_PATH)):
+    for k, co in enumerate(_gfx950_code_objects(lib_path)):
         f = tmp_path / ("co%d.elf" % k)
         f.write_bytes(co)
-        txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True).stdout
-        if "optimize_kernelILi8ELi2E" not in txt:
-            continue
-        for sym in ("optimize_kernelILi8ELi2E", "optimize_kernelILi8ELi4E"):
+        yield subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True).stdout
+
+
+def test_split_cloud_arrivals_are_preceded_by_a_vmcnt0_wait(lib, tmp_path):
+    """Round-3 advisor finding: a member of a split cloud must drain its stores / atomics to the exchange block
+    (`s_waitcnt vmcnt(0)`, knn_device.h coop_publish) before it bumps an arrival counter - the workgroup-scope release
+    fence alone emits no vmcnt wait on gfx950.  Checked in the shipped ISA: in optimize_kernel<8, 2, P> and <8, 4, P> (P = 0: f32
+    tiles, 1 / 2: the split-precision tiles) the nearest preceding memory-write-or-wait of every arrival atomic (a 32-bit
+    global_atomic_add through an SGPR base) is the wait."""
+    import ifdefense_amd as I
+    found = {}
+    for txt in _disassemblies(I.LIB_PATH, tmp_path):
+        for sym in sorted(set(re.findall(r"<_ZN3ifd15(optimize_kernelILi8ELi[24]ELi[012]E)", txt))):
             body = txt[txt.index("<_ZN3ifd15" + sym):]
             body = body[:body.index("s_endpgm")]
             ins = [l.split("//")[0].strip() for l in body.splitlines()]
@@ -225,4 +228,26 @@ def test_split_cloud_arrivals_are_preceded_by_a_vmcnt0_wait(lib, tmp_path):
                             if l.startswith(("global_store", "global_atomic", "s_waitcnt vmcnt(0)")) or "vmcnt(0)" in l)
                 assert "vmcnt(0)" in prev and prev.startswith("s_waitcnt"), (sym, ins[max(0, a - 12):a + 1])
             found[sym] = len(arrivals)
-    assert len(found) == 2, "optimize_kernel<8,2> / <8,4> not found in libifd.so"
+    assert len(found) == 6, "optimize_kernel<8, 2 | 4, 0 | 1 | 2> not all found in libifd.so: %s" % sorted(found)
+
+
+def test_no_packed_f32_result_is_read_across_a_bare_waitcnt(lib, tmp_path):
+    """Round 5: hipcc (ROCm 7.2) pads a packed-f32 producer -> dependent vector consumer pair with one wait state and counts an
+    s_waitcnt that stands between the two as that state; gfx950 spends no cycle on a wait whose condition already holds, and the
+    consumer then reads the old register (scripts/pk_waitcnt_hazard.hip; it made ~1 % of the split-precision tile's first
+    sub-tiles wrong, run to run).  No optimiser or encoder kernel of the shipped library may contain the pattern where the wait
+    can already be satisfied; the known remaining sites wait for a spill reload or scalar load issued just before (listed)."""
+    import importlib.util
+    import ifdefense_amd as I
+    spec = importlib.util.spec_from_file_location("asm_pk_hazard", os.path.join(ROOT, "scripts", "asm_pk_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = {}
+    n_kernels = 0
+    for txt in _disassemblies(I.LIB_PATH, tmp_path):
+        n_kernels += len(re.findall(r"^[0-9a-f]+ <_ZN3ifd", txt, flags=re.M))
+        bad.update(mod.scan(txt.split("\n")))
+    assert n_kernels >= 30, n_kernels
+    allowed = ("encode_points_kernel",)       # the thread-per-point encoder kept for validation (IFD_ENC_VALU=1): waits on scalar loads
+    bad = {k: v for k, v in bad.items() if not any(a in k for a in allowed)}
+    assert not bad, {k: v[:2] for k, v in bad.items()}
