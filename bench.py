@@ -7,12 +7,16 @@
 One "step" = one pass of the whole hot path (SOR -> preprocess/subset/init -> encoder -> 501 Adam steps ->
 normalise -> all-gather) over one batch of synthetic ModelNet40-test-like input: 2468 clouds x 1024 points per
 GPU (BASELINE.json configs[1]; weak scaling: every rank restores its own 2468 clouds of a 2468*N array).
-Inputs are resident in HBM when the timed region starts; weights are seeded random (the trained checkpoint
-and ModelNet40 are downloads).  Prints ONE JSON line on rank 0.
+`value` is BASELINE configs[1] taken literally: ONE file at a time, a device synchronisation after every file - no pass
+rides on another's tail (round-4 verdict).  The same passes driven as a stream of files (the next file's pre-processing on a
+second HIP stream under the optimiser's last round: a directory of .npz files through the CLI) are `extras.streamed`
+(`--streamed` makes that the timed mode).  Inputs are resident in HBM when the timed region starts; weights are seeded
+random (the trained checkpoint and ModelNet40 are downloads).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -131,7 +135,7 @@ def kernel_source_sha():
     """Hash of the optimiser kernel's sources (the stamp scripts/summarise_profiles.py puts on roofline_traffic.json)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("optimize.hip", "knn_device.h", "ifd_device.h"):
+    for f in ("optimize.hip", "optimize_kernel.h", "knn_device.h", "ifd_device.h"):
         h.update(open(os.path.join(ROOT, "if-defense_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -181,6 +185,94 @@ def cpu_baseline(clouds, n_sample=16, budget_s=15.0, onet=False, full_run_clouds
         t_full = time.perf_counter() - t0
         out["full_run"] = {"clouds": full_run_clouds, "adam_steps": ITERATIONS + 1, "seconds": round(t_full, 2),
                            "clouds_per_s": round(full_run_clouds / (t_full + t_pre * full_run_clouds / n_sample), 4)}
+    return out
+
+
+def _cpu_worker(job):
+    """One worker of the host-saturating CPU figure: the oracle's optimiser loop on its own clouds, `threads` intra-op threads."""
+    seed, n, steps, threads = job
+    import torch as T
+    T.set_num_threads(threads)
+    from oracle import convonet_oracle as O
+    w = O.to_torch(O.make_random_weights(0))
+    g = T.Generator().manual_seed(seed)
+    v = T.randn(n, K_POINTS, 3, generator=g)
+    init = 0.4 * v / v.norm(dim=-1, keepdim=True) + 0.01 * T.randn(n, K_POINTS, 3, generator=g)
+    planes = {k: 0.5 * T.randn(n, 32, 64, 64, generator=g) for k in ("xz", "xy", "yz")}
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=0, normalize=False)      # warm-up step
+    t0 = time.perf_counter()
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=steps - 1, normalize=False)
+    return (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline_saturating(base, budget_s=20.0):
+    """Two host-SATURATING figures next to the 16-thread one (round-4 verdict): (i) floor(cores / 16) concurrent 16-thread workers on
+    disjoint 16-cloud batches, (ii) the reference's own batch of 192 clouds in ONE process at os.cpu_count() threads (BASELINE.md
+    section 3's setting).  Optimiser loop only (96 % of the path's CPU time), a few steps each, scaled to 501; bounded."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    out = {}
+    per_step_16 = None
+    try:
+        m = re.search(r"(\d+) of \d+ Adam steps \(([0-9.]+) s\)", base["sample"])
+        per_step_16 = float(m.group(2)) / int(m.group(1))
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        workers = max(1, cores // 16)
+        steps = 3 if per_step_16 is None else int(max(2, min(10, budget_s / (3.0 * per_step_16))))
+        with mp.get_context("spawn").Pool(workers) as pool:
+            t0 = time.perf_counter()
+            per = pool.map(_cpu_worker, [(100 + i, 16, steps, 16) for i in range(workers)])
+            wall = time.perf_counter() - t0
+        slowest = max(per)
+        out["workers_x16_threads"] = {
+            "value": round(workers * 16 / (slowest * (ITERATIONS + 1)), 4), "unit": "clouds/s", "cores": workers * 16, "workers": workers,
+            "sample": "%d concurrent workers x 16 threads x 16 clouds, %d Adam steps each (slowest worker %.2f s per step, pool wall "
+                      "%.1f s incl. start-up), optimiser loop only, scaled to %d steps" % (workers, steps, slowest, wall, ITERATIONS + 1)}
+    except Exception as e:      # noqa: BLE001
+        out["workers_x16_threads"] = {"error": str(e)[:200]}
+    try:
+        t0 = time.perf_counter()
+        per = _cpu_worker((7, 192, 1, cores))
+        out["batch192_all_threads"] = {
+            "value": round(192 / (per * (ITERATIONS + 1)), 4), "unit": "clouds/s", "cores": cores,
+            "sample": "ONE process, torch.set_num_threads(%d), the reference's batch of 192 clouds: 1 warm-up + 1 timed Adam step (%.2f s), "
+                      "optimiser loop only, scaled to %d steps (%.1f s in all)" % (cores, per, ITERATIONS + 1, time.perf_counter() - t0)}
+    except Exception as e:      # noqa: BLE001
+        out["batch192_all_threads"] = {"error": str(e)[:200]}
+    return out
+
+
+def split_precision_extras(r, x, args, lo, total, ev):
+    """the whole path with the decoder's dense layers on the bf16 matrix core (ifd_opt_params.precision, csrc/tile_bf.h),
+    two files each, one at a time like the headline.  bf16x6 = both operands split exactly into three bf16 pieces, six piece products:
+    f32-equivalent arithmetic (held to the f32 tile's bars in tests/test_gpu_split_precision.py); bf16x3 = REDUCED precision.
+    Neither is the headline."""
+    import ifdefense_amd as I
+    out = {}
+    for mode in ("bf16x6", "bf16x3"):
+        os.environ["IFD_PRECISION"] = mode
+        try:
+            for _ in I.defend_stream(r, [x], args, bases=[lo], totals=[total], overlap=False):
+                pass
+            torch.cuda.synchronize()
+            ev.clear()
+            t0 = time.perf_counter()
+            for _ in I.defend_stream(r, [x] * 2, args, bases=[lo] * 2, totals=[total] * 2, overlap=False):
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) / max(1, len(ev))
+            out[mode] = {"value": round(total / dt, 1), "unit": "clouds/s", "ms_per_file": round(dt * 1e3, 1), "optimiser_launch_ms": round(ms, 1),
+                         "f32_equivalent_tflops": round(FLOP_DENSE_PER_CLOUD * total / (ms * 1e-3) / 1e12, 1),
+                         "precision": "f32-equivalent (three exact bf16 pieces per operand, six products, f32 accumulation)" if mode == "bf16x6"
+                                      else "REDUCED (two pieces, three products: 2^-17 per product)"}
+        except Exception as e:      # noqa: BLE001
+            out[mode] = {"error": str(e)[:200]}
+        finally:
+            os.environ.pop("IFD_PRECISION", None)
+    out["what"] = ("opt-in arithmetic of the decoder's 32 x 32 layers, never the headline: one 2468-cloud file at a time, mean of 2; "
+                   "f32_equivalent_tflops = algorithmic decoder FLOPs / optimiser launch time (the f32-MFMA peak is 157.3)")
     return out
 
 
@@ -330,7 +422,10 @@ def main():
                     help="weak (default): every rank restores its own --clouds clouds; strong: ONE array of --clouds clouds is "
                          "sharded over the ranks (BASELINE configs #3 / #5: one .npz over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="serial passes (no second stream for the next pass's pre-processing)")
+    ap.add_argument("--streamed", action="store_true",
+                    help="time the K passes as a STREAM of K files (pre-processing of file n + 1 on a second HIP stream under file n's "
+                         "optimiser tail) instead of one file at a time with a synchronisation after each (the default: BASELINE configs[1])")
+    ap.add_argument("--no-overlap", action="store_true", help="(kept for scripts: the default since round 5) one file at a time")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements (reference-style unfused "
                     "GPU baseline, ONet-Opt, ONet-Mesh) that ride along in the N = 1 line")
     ap.add_argument("--dry-run", action="store_true",
@@ -341,6 +436,7 @@ def main():
                     help="convonet-opt = the BASELINE metric (default); onet-opt = the ONet-Opt decoder variant "
                          "(BASELINE config #1 model, SURVEY N4) at 500 iterations - an extra line, not the headline")
     a = ap.parse_args()
+    a.no_overlap = not a.streamed
     onet = a.workload == "onet-opt"
     if onet and a.clouds == N_CLOUDS:
         a.clouds = 256                                                  # one cloud per CU; ~3 s per step
@@ -413,6 +509,8 @@ def main():
             full = D.gather_shards(local_out, total, per)               # the one collective of the path (RCCL all-gather)
             g1.record()
             gev.append((g0, g1))
+            if a.no_overlap:
+                torch.cuda.synchronize()                                # one file at a time: its result is complete before the next starts
         return full
 
     def barrier():
@@ -463,8 +561,11 @@ def main():
                                    "normalise+gather" % ("ONet-Opt" if onet else "ConvONet-Opt", per),
                        "clouds_per_gpu": per, "clouds_total": total, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
                        "parallelism": "shard%d+allgather" % world, "weights": "seeded random (seed 0)",
-                       "driver": "passes streamed: pre-processing of pass n+1 on a second HIP stream under pass n's optimiser tail"
-                                 if not a.no_overlap else "serial passes"},
+                       "driver": "stream of %d files: pre-processing of file n+1 on a second HIP stream under file n's optimiser tail" % a.steps
+                                 if not a.no_overlap else "one file at a time, device synchronisation after every file (BASELINE configs[1] literally)",
+                       "arith": "f32 throughout; decoder layers on v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain); repulsion terms' "
+                                "sqrt / 1/h / 1/d / exp through the 1-ulp hardware instructions (IFD_EXACT_REP off; libifd_exact.so has the "
+                                "IEEE expansions, +1.3 %); ReLU'(+0.0) passes in the hot tile (DESIGN section 10)"},
             "roofline": {"bound": "mfma", "kernel": "ifd::onet_optimize_kernel" if onet else "ifd::optimize_kernel",
                          "achieved": round(achieved, 2),
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
@@ -473,21 +574,27 @@ def main():
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
             "gather_ms": round(sum(g0.elapsed_time(g1) for g0, g1 in gev) / max(1, len(gev)), 3),
         }
-        if world == 1 and not onet and not a.no_extras and not a.no_overlap:
-            # BASELINE configs[1] is ONE file: the literal single-file case (no later pass whose pre-processing could ride on
-            # the optimiser's tail), three serial passes, driver-timed in every run
+        streamed = None
+        if world == 1 and not onet and not a.no_extras and a.no_overlap:
+            # the same passes as a stream of files (what a directory of .npz files through the CLI does): five passes, driver-timed
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in I.defend_stream(r, [x] * 3, args, bases=[lo] * 3, totals=[total] * 3, overlap=False):
-                torch.cuda.synchronize()
-            dt1 = (time.perf_counter() - t1) / 3
-            res["single_file"] = {"value": round(total / dt1, 2), "unit": "clouds/s", "ms_per_file": round(dt1 * 1e3, 2),
-                                  "what": "one 2468-cloud file at a time (--no-overlap semantics, a device synchronisation "
-                                          "after every file), mean of 3: BASELINE configs[1] taken literally"}
+            for _ in I.defend_stream(r, [x] * 5, args, bases=[lo] * 5, totals=[total] * 5, overlap=True):
+                pass
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / 5
+            streamed = {"value": round(total / dt1, 2), "unit": "clouds/s", "ms_per_file": round(dt1 * 1e3, 2),
+                        "what": "the same workload driven as a stream of 5 files: pre-processing of file n+1 on a second HIP stream under "
+                                "file n's last optimiser round (a directory input of the CLI); the first file has nothing to hide under"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(my_clouds, onet=onet, full_run_clouds=0 if onet else 4)
+            if not onet:
+                res["cpu_baseline"]["host_saturating"] = cpu_baseline_saturating(res["cpu_baseline"])
         if world == 1 and not onet and not a.no_extras:
             res["extras"] = extras(dev)
+            if streamed is not None:
+                res["extras"]["streamed"] = streamed
+            res["extras"]["split_precision"] = split_precision_extras(r, x, args, lo, total, ev)
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

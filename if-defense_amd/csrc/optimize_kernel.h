@@ -1239,8 +1239,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
 #ifdef IFD_TRACE2
                 unsigned long long* tr2 = (cn.pc != nullptr && trace_tile == IFD_TRACE2) ? counters + TRACE2_BASE + wave * 128 : nullptr;
                 if (tr2 != nullptr && lane == 0) tr2[71] = (unsigned long long)tile;
-                decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
-                                        A.threshold, inv_lb, want_loss, bce, dx, tr2);
+                if (PREC == 0)
+                    decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
+                                            A.threshold, inv_lb, want_loss, bce, dx, tr2);
+                else
+                    decoder_tile3_bf<MODE_OPT, PREC>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
+                                                     A.threshold, want_loss, bce, dx, tr2);
 #else
                 if (PREC == 0)
                     decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
@@ -1304,6 +1308,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             }
         }
         if (S == 1 || IFD_SPLIT_KNN_PRIO != 0) { PROF_T0(); run_tiles(); }
+        if (PREC != 0) asm volatile("s_setprio 0");          // (the split-precision tile leaves its edge priority set)
         PROF_ACC(pc_tiles);
 // [pcsamp:step.adam]
         // ---- Adam: its state comes back from scratch under the barrier wait ------------------------------------------------

@@ -76,26 +76,133 @@ __device__ __forceinline__ void split_bf(const f32x8& x, const SelMat& sel, Piec
     }
 }
 
-// acc += W x from the pieces, small terms first; the two M-tiles are independent accumulator chains
+// acc += W x from the pieces, small terms first; the two M-tiles are independent accumulator chains.  Term k multiplies weight
+// piece TA[k] by activation piece TP[k]:  bf16x6: w3 x1, w1 x3, w2 x2, w2 x1, w1 x2, w1 x1;  bf16x3: w2 x1, w1 x2, w1 x1.
+template <int PREC>
+__device__ __forceinline__ void dense_terms(const WFragBF& A, const Pieces& P, Acc2& acc, int k0, int k1) {
+    constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TP6[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int TA3[3] = {1, 0, 0}, TP3[3] = {0, 1, 0};
+#pragma unroll
+    for (int k = k0; k < k1; ++k) {
+        const int ta = PREC == 1 ? TA6[k] : TA3[k], tp = PREC == 1 ? TP6[k] : TP3[k];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[ta][mt], P.p[tp], acc.t[mt]);
+    }
+}
 template <int PREC>
 __device__ __forceinline__ void dense_bf(const WFragBF& A, const Pieces& P, Acc2& acc) {
-    if (PREC == 1) {
+    dense_terms<PREC>(A, P, acc, 0, PREC == 1 ? 6 : 3);
+}
+
+// One software-pipeline region: the 12 (6) MFMAs of one sub-tile's layer (acc += A Pin) beside the epilogue of the other's - its
+// vector instructions in NS stages of <= 4 (epi(stage, x): bias / ReLU / mask), then the split of x into Pout, whose residual
+// MFMAs and conversions are dealt between the layer's MFMAs.  The matrix pipe takes one v_mfma_f32_16x16x32_bf16 per 16
+// cycles and the vector pipe runs beside it, so the stream alternates ONE MFMA with <= 4 vector instructions and puts >= 2
+// other MFMAs between a residual MFMA and the conversion that reads it: a lone wave then keeps the matrix pipe busy (an in-order
+// wave only overlaps what is adjacent in its instruction stream; left to itself hipcc issues the twelve MFMAs first and the
+// split chain behind them with ~25 wait states between its steps).  The order is pinned with scheduling barriers.
+#define BF_SB() __builtin_amdgcn_sched_barrier(0)
+// Wave priorities (a tuning knob, off by default: measured within 2 %): the sections around the MLP at IFD_BF_PRIO_EDGE, the MLP
+// sections at IFD_BF_PRIO_MLP.
+#ifndef IFD_BF_PRIO_EDGE
+#define IFD_BF_PRIO_EDGE 0
+#endif
+#ifndef IFD_BF_PRIO_MLP
+#define IFD_BF_PRIO_MLP 0
+#endif
+#define BF_PRIO_STR2(x) #x
+#define BF_PRIO_STR(x) BF_PRIO_STR2(x)
+#define BF_PRIO(p) do { if (IFD_BF_PRIO_EDGE != IFD_BF_PRIO_MLP) asm volatile("s_setprio " BF_PRIO_STR(p)); } while (0)
+template <int PREC>
+__device__ __forceinline__ void dense_one(const WFragBF& A, const Pieces& P, Acc2& acc, int k) {        // MFMA k of the layer: term k / 2, M-tile k % 2
+    constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TP6[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int TA3[3] = {1, 0, 0}, TP3[3] = {0, 1, 0};
+    const int t = k >> 1, mt = k & 1;
+    const int ta = PREC == 1 ? TA6[t] : TA3[t], tp = PREC == 1 ? TP6[t] : TP3[t];
+    acc.t[mt] = mfma_bf(A.a[ta][mt], P.p[tp], acc.t[mt]);
+    BF_SB();
+}
+__device__ __forceinline__ void cvt4_bf(bf16x8& o, const f32x4& v, int h) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[2][mt], P.p[0], acc.t[mt]);
+    for (int j = 0; j < 4; ++j) o[4 * h + j] = (__bf16)v[j];
+    BF_SB();
+}
+template <int PREC, int NS, typename Epi>
+__device__ __forceinline__ void region_bf(const WFragBF& A, const Pieces& Pin, Acc2& acc, const SelMat& sel, Pieces& Pout, Epi epi) {
+    f32x8 x;
+    int d = 0;                                     // next MFMA of the layer
+    BF_SB();
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[0][mt], P.p[2], acc.t[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[1][mt], P.p[1], acc.t[mt]);
+    for (int st = 0; st < NS; ++st) {              // the epilogue's stages, one MFMA in front of each
+        dense_one<PREC>(A, Pin, acc, d++);
+        epi(st, x);
+        BF_SB();
     }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[1][mt], P.p[0], acc.t[mt]);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[0][mt], P.p[1], acc.t[mt]);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc.t[mt] = mfma_bf(A.a[0][mt], P.p[0], acc.t[mt]);
+    f32x4 c0 = {x[0], x[1], x[2], x[3]}, c1 = {x[4], x[5], x[6], x[7]};
+    dense_one<PREC>(A, Pin, acc, d++);
+    cvt4_bf(Pout.p[0], c0, 0);
+    if (PREC == 1 || NS < 4) dense_one<PREC>(A, Pin, acc, d++);
+    cvt4_bf(Pout.p[0], c1, 1);
+    c0 = mfma_bf(sel.m[0], Pout.p[0], c0);         // residual 1 ...
+    BF_SB();
+    c1 = mfma_bf(sel.m[1], Pout.p[0], c1);
+    BF_SB();
+    dense_one<PREC>(A, Pin, acc, d++);             // ... its latency under the layer's next MFMAs
+    if (PREC == 1) {
+        dense_one<PREC>(A, Pin, acc, d++);
+        cvt4_bf(Pout.p[1], c0, 0);
+        dense_one<PREC>(A, Pin, acc, d++);
+        cvt4_bf(Pout.p[1], c1, 1);
+        c0 = mfma_bf(sel.m[0], Pout.p[1], c0);     // residual 2
+        BF_SB();
+        c1 = mfma_bf(sel.m[1], Pout.p[1], c1);
+        BF_SB();
+        while (d < 11) dense_one<PREC>(A, Pin, acc, d++);
+        cvt4_bf(Pout.p[2], c0, 0);
+        dense_one<PREC>(A, Pin, acc, d++);
+        cvt4_bf(Pout.p[2], c1, 1);
+        while (d < 12) dense_one<PREC>(A, Pin, acc, d++);
+    } else {
+        while (d < 6) dense_one<PREC>(A, Pin, acc, d++);
+        cvt4_bf(Pout.p[1], c0, 0);
+        cvt4_bf(Pout.p[1], c1, 1);
+        Pout.p[2] = Pout.p[1];
+    }
+    BF_SB();
 }
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+// The epilogues of region_bf in stages of <= 4 vector instructions.  Forward: ReLU (one v_max_i32 per value, relu8) and the sign-byte
+// mask of decoder_tile3 (mask_alive_packed: two v_perm + one v_xnor per four values); backward: the mask applied (one SDWA
+// v_and per value, masked()), for the a-masks followed by the residual add.
+__device__ __forceinline__ void relu_mask_stage(const Acc2& a, Mask8& m, int st, f32x8& x) {
+    if (st < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[4 * st + r] = __int_as_float(max(__float_as_int(a.t[st][r]), 0));
+    } else {
+        const int h = st - 2;
+        const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(a.t[h][0]), __float_as_uint(a.t[h][1]), 0x0b090c0cu);
+        const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(a.t[h][2]), __float_as_uint(a.t[h][3]), 0x0c0c0b09u);
+        uint32_t w = ~(hi ^ lo);
+        asm volatile("" : "+v"(w));
+        m.w[h] = w;
+    }
+}
+__device__ __forceinline__ void masked_stage(const Acc2& z, const Mask8& m, int st, f32x8& x) {
+    x[4 * st + 0] = keep_alive<3>(z.t[st][0], m.w[st]); x[4 * st + 1] = keep_alive<2>(z.t[st][1], m.w[st]);
+    x[4 * st + 2] = keep_alive<1>(z.t[st][2], m.w[st]); x[4 * st + 3] = keep_alive<0>(z.t[st][3], m.w[st]);
+}
+__device__ __forceinline__ void masked_add_stage(const Acc2& y, const Mask8& m, f32x8& dn, int st, f32x8& x) {
+    const int h = st >> 1;
+    if ((st & 1) == 0) {
+        x[4 * h + 0] = keep_alive<3>(y.t[h][0], m.w[h]); x[4 * h + 1] = keep_alive<2>(y.t[h][1], m.w[h]);
+        x[4 * h + 2] = keep_alive<1>(y.t[h][2], m.w[h]); x[4 * h + 3] = keep_alive<0>(y.t[h][3], m.w[h]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dn[4 * h + r] += x[4 * h + r]; x[4 * h + r] = dn[4 * h + r]; }
+    }
+}
 
 // (scalar: no packed-f32 instructions in this tile, see decoder_tile3_bf)
 __device__ __forceinline__ Acc2 acc_add_s(const Acc2& a, const Acc2& b) {
@@ -147,7 +254,10 @@ __device__ __forceinline__ WFragBF load_wfrag_bf(const lds_u8* __restrict__ Wb, 
 template <int MODE, int PREC>
 __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, __amdgpu_buffer_rsrc_t planes,
                                                  const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, int lane,
-                                                 const DecConst dc, float thr, bool want_loss, float (&bce)[2], float (&dx)[2][3]) {
+                                                 const DecConst dc, float thr, bool want_loss, float (&bce)[2], float (&dx)[2][3],
+                                                 [[maybe_unused]] unsigned long long* tr = nullptr) {
+    T2(0);                                       // (-DIFD_TRACE2 stamps: decoder_tile3's slot map, scripts/tile_trace.py)
+    BF_PRIO(IFD_BF_PRIO_EDGE);
     const lds_u8* Wb = (const lds_u8*)Wg;
     const int n = lane & 15, q = lane >> 4;
     int lane_off = lane * BF_ENTRY_BYTES;
@@ -177,8 +287,20 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
 #pragma unroll
         for (int r = 0; r < 8; ++r) c[t][r] = 0.f;
     const int q16 = 16 * q;
+#ifndef IFD_BF_TIMING_NOGATHER
+#define IFD_BF_TIMING_NOGATHER 0      // timing experiments with WRONG results: 1 no backward re-gather, 2 no gather at all
+#endif
     auto load_taps = [&](int P, f32x4 (&tap)[2][4][2], bool opaque) {
         const int a0 = AX0[P], a1 = AX1[P];
+        if ((IFD_BF_TIMING_NOGATHER == 1 && opaque) || IFD_BF_TIMING_NOGATHER == 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) tap[t][k][mt] = f32x4{geo[t].w0[a0], geo[t].w1[a1], 0.5f, 0.25f};
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             int off = (geo[t].cell[a1] * RES + geo[t].cell[a0]) * (CH * 4) + (P * PLANE_FLOATS * 4 + q16);
@@ -226,6 +348,11 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         load_taps(1, tap1, false);
         load_taps(2, tap2, false);
         __builtin_amdgcn_sched_barrier(0);
+        T2(1);
+#ifdef IFD_TRACE2
+        if (tr != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        T2(2);
+#endif
         // one explicit wait per plane (s_waitcnt vmcnt(32) / (16) / (0): the planes' 16 loads each, oldest first) instead of hipcc's
         // load-by-load waits inside the multiply-add chains
         __builtin_amdgcn_s_waitcnt(0x8F70);
@@ -240,6 +367,7 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         __builtin_amdgcn_sched_barrier(0);
         sample_fwd(2, tap2);
         __builtin_amdgcn_sched_barrier(0);
+        T2(3);
     }
 
     const SelMat sel = make_selmat(lane);
@@ -259,6 +387,8 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     split_bf<PREC>(c[0], sel, PC[0]);
     split_bf<PREC>(c[1], sel, PC[1]);
     __builtin_amdgcn_sched_barrier(0);
+    T2(4);
+    BF_PRIO(IFD_BF_PRIO_MLP);
 
     // ---- forward MLP -----------------------------------------------------------------------------------------------
     Mask8 mask_a[2][NBLK], mask_h[2][NBLK];
@@ -272,43 +402,24 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         // fc_c: a = n + fc_c(c)   (bias folded into n)
         Acc2 a0 = net[0], a1 = net[1];
         dense_bf<PREC>(A, PC[0], a0);                                          // R1
-        __builtin_amdgcn_sched_barrier(0);
+        BF_SB();
+        T2(5 + 6 * i + 0);
         const WFragBF A0 = load_wfrag_bf<false, PREC>(Wb, 3 * i + 1, lane_off, lane_off_t);   // R2: prefetch fc_0
         const Acc2 B0 = bias(3 * i + 1);
-        dense_bf<PREC>(A, PC[1], a1);
         Pieces PA0, PA1, PH0, PH1;
-        {
-            f32x8 ra;
-            relu_and_mask(flat(a0), c31, sc2, ra, mask_a[0][i]);
-            split_bf<PREC>(ra, sel, PA0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        region_bf<PREC, 4>(A, PC[1], a1, sel, PA0, [&](int st, f32x8& x) { relu_mask_stage(a0, mask_a[0][i], st, x); });
+        T2(5 + 6 * i + 1);
         Acc2 h0 = B0;                                                          // R3
-        dense_bf<PREC>(A0, PA0, h0);
-        {
-            f32x8 ra;
-            relu_and_mask(flat(a1), c31, sc2, ra, mask_a[1][i]);
-            split_bf<PREC>(ra, sel, PA1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        region_bf<PREC, 4>(A0, PA0, h0, sel, PA1, [&](int st, f32x8& x) { relu_mask_stage(a1, mask_a[1][i], st, x); });
+        T2(5 + 6 * i + 2);
         const WFragBF A1 = load_wfrag_bf<false, PREC>(Wb, 3 * i + 2, lane_off, lane_off_t);   // R4: prefetch fc_1
         const Acc2 B1 = bias(3 * i + 2);
         Acc2 h1 = B0;
-        dense_bf<PREC>(A0, PA1, h1);
-        {
-            f32x8 rh;
-            relu_and_mask(flat(h0), c31, sc2, rh, mask_h[0][i]);
-            split_bf<PREC>(rh, sel, PH0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        Acc2 o0 = acc_add_s(B1, a0);                                             // R5
-        dense_bf<PREC>(A1, PH0, o0);
-        {
-            f32x8 rh;
-            relu_and_mask(flat(h1), c31, sc2, rh, mask_h[1][i]);
-            split_bf<PREC>(rh, sel, PH1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        region_bf<PREC, 4>(A0, PA1, h1, sel, PH0, [&](int st, f32x8& x) { relu_mask_stage(h0, mask_h[0][i], st, x); });
+        T2(5 + 6 * i + 3);
+        Acc2 o0 = acc_add_s(B1, a0);                                           // R5
+        region_bf<PREC, 4>(A1, PH0, o0, sel, PH1, [&](int st, f32x8& x) { relu_mask_stage(h1, mask_h[1][i], st, x); });
+        T2(5 + 6 * i + 4);
         if (i + 1 < NBLK) {                                                    // R6: prefetch the next fc_c / the first fc_1^T
             A = load_wfrag_bf<false, PREC>(Wb, 3 * i + 3, lane_off, lane_off_t);
         } else {
@@ -325,9 +436,11 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         dense_bf<PREC>(A1, PH1, o1);
         net[0] = o0;
         net[1] = o1;
-        __builtin_amdgcn_sched_barrier(0);
+        BF_SB();
+        T2(5 + 6 * i + 5);
     }
     // ---- logit, loss derivative, seed of the backward pass (decoder_tile3's) ---------------------------------------------
+    BF_PRIO(IFD_BF_PRIO_EDGE);
     f32x8 dn[2];
     Pieces PD[2];
 #pragma unroll
@@ -359,6 +472,8 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         split_bf<PREC>(dn[t], sel, PD[t]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    T2(35);
+    BF_PRIO(IFD_BF_PRIO_MLP);
 
     // ---- backward (A holds fc_1[4]^T) --------------------------------------------------------------------------------------
     Acc2 dcc[2] = {acc_zero(), acc_zero()};
@@ -366,38 +481,34 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     for (int i = NBLK - 1; i >= 0; --i) {
         Acc2 z0 = acc_zero();                                                  // R1: fc_1^T dn (sub-tile 0)
         dense_bf<PREC>(A, PD[0], z0);
-        __builtin_amdgcn_sched_barrier(0);
+        BF_SB();
+        T2(36 + 6 * (NBLK - 1 - i) + 0);
         const WFragBF A0 = load_wfrag_bf<true, PREC>(Wb, 3 * i + 1, lane_off, lane_off_t);    // R2: prefetch fc_0^T
         Acc2 z1 = acc_zero();
-        dense_bf<PREC>(A, PD[1], z1);
         Pieces PH0, PH1;
-        split_bf<PREC>(masked(z0, mask_h[0][i]), sel, PH0);
-        __builtin_amdgcn_sched_barrier(0);
+        region_bf<PREC, 2>(A, PD[1], z1, sel, PH0, [&](int st, f32x8& x) { masked_stage(z0, mask_h[0][i], st, x); });
+        T2(36 + 6 * (NBLK - 1 - i) + 1);
         Acc2 y0 = acc_zero();                                                  // R3: fc_0^T dh (sub-tile 0)
-        dense_bf<PREC>(A0, PH0, y0);
-        split_bf<PREC>(masked(z1, mask_h[1][i]), sel, PH1);
-        __builtin_amdgcn_sched_barrier(0);
+        region_bf<PREC, 2>(A0, PH0, y0, sel, PH1, [&](int st, f32x8& x) { masked_stage(z1, mask_h[1][i], st, x); });
+        T2(36 + 6 * (NBLK - 1 - i) + 2);
         const WFragBF Ac = load_wfrag_bf<true, PREC>(Wb, 3 * i, lane_off, lane_off_t);        // R4: prefetch fc_c^T
         Acc2 y1 = acc_zero();
-        dense_bf<PREC>(A0, PH1, y1);
+        region_bf<PREC, 4>(A0, PH1, y1, sel, PD[0], [&](int st, f32x8& x) { masked_add_stage(y0, mask_a[0][i], dn[0], st, x); });   // delta a_i
+        T2(36 + 6 * (NBLK - 1 - i) + 3);
+        // R5: dc += fc_c^T da (sub-tile 0)
         {
-            const f32x8 t = masked(y0, mask_a[0][i]);
-            add8_s(dn[0], t);                                                 // delta a_i
-            split_bf<PREC>(dn[0], sel, PD[0]);
+            Pieces PD1;
+            region_bf<PREC, 4>(Ac, PD[0], dcc[0], sel, PD1, [&](int st, f32x8& x) { masked_add_stage(y1, mask_a[1][i], dn[1], st, x); });
+            PD[1] = PD1;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        dense_bf<PREC>(Ac, PD[0], dcc[0]);                                     // R5: dc += fc_c^T da (sub-tile 0)
-        {
-            const f32x8 t = masked(y1, mask_a[1][i]);
-            add8_s(dn[1], t);
-            split_bf<PREC>(dn[1], sel, PD[1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        T2(36 + 6 * (NBLK - 1 - i) + 4);
         if (i > 0) A = load_wfrag_bf<true, PREC>(Wb, 3 * i - 1, lane_off, lane_off_t);        // R6: prefetch fc_1[i-1]^T
         dense_bf<PREC>(Ac, PD[1], dcc[1]);
-        __builtin_amdgcn_sched_barrier(0);
+        BF_SB();
+        T2(36 + 6 * (NBLK - 1 - i) + 5);
     }
     // ---- fc_p backward and d c / d u through the re-gathered taps (decoder_tile3's) -----------------------------------------
+    BF_PRIO(IFD_BF_PRIO_EDGE);
     float g[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t) g[t][0] = g[t][1] = g[t][2] = 0.f;
@@ -443,9 +554,15 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     };
     {
         f32x4 btap0[2][4][2], tap1[2][4][2], tap2[2][4][2];
+        T2(66);
         load_taps(0, btap0, true);
         load_taps(1, tap1, true);
         __builtin_amdgcn_sched_barrier(0);
+        T2(67);
+#ifdef IFD_TRACE2
+        if (tr != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        T2(68);
+#endif
         __builtin_amdgcn_s_waitcnt(0x4F70);      // (whole planes, as in the forward gather)
         __builtin_amdgcn_sched_barrier(0);
         sample_bwd(0, btap0);
@@ -460,9 +577,11 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         __builtin_amdgcn_sched_barrier(0);
         sample_bwd(2, tap2);
         __builtin_amdgcn_sched_barrier(0);
+        T2(69);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int a = 0; a < 3; ++a) dx[t][a] = add_lane_xor32(add_lane_xor16(g[t][a]));
+    T2(70);
 }

@@ -331,7 +331,7 @@ class Restorer:
     def tile_trace(self):
         """Time stamps (shader cycles) inside ONE decoder tile per wave of the traced step, [8 waves][128 slots] - only filled
         by a -DIFD_TRACE -DIFD_TRACE2=<n> diagnostic build (scripts/tile_trace.py; slot map in optimize.hip decoder_tile3)."""
-        base = 16 + 8 * 32 + 2
+        base = 16 + 8 * 32 + 3          # behind the three status words (ifd_internal.h TRACE2_BASE)
         buf = (C.c_uint64 * (base + 8 * 128))()
         self._check(self.lib.ifd_get_counters(self.ctx, buf, base + 8 * 128))
         return [[int(buf[base + w * 128 + i]) for i in range(128)] for w in range(8)]
