@@ -29,7 +29,7 @@ class IfdOptParams(C.Structure):
                 ("loss_batch", C.c_int32), ("normalize", C.c_int32), ("lr", C.c_float),
                 ("rep_weight", C.c_float), ("threshold", C.c_float), ("rep_radius", C.c_float),
                 ("rep_h", C.c_float), ("rep_eps", C.c_float), ("knn_scan_every_step", C.c_int32),
-                ("split", C.c_int32), ("planes_shared", C.c_int32), ("precision", C.c_int32)]
+                ("split", C.c_int32), ("planes_shared", C.c_int32), ("knn_reference_form", C.c_int32), ("precision", C.c_int32)]
 
 
 class IfdPrepParams(C.Structure):

@@ -654,7 +654,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
     OptArgs a{};
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
-    a.knn_scan_every_step = prm->knn_scan_every_step;
+    a.knn_scan_every_step = prm->knn_reference_form ? 2 : (prm->knn_scan_every_step ? 1 : 0);
     a.planes_shared = prm->planes_shared;
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
@@ -871,7 +871,7 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
     OptArgs a{};
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
-    a.knn_scan_every_step = prm->knn_scan_every_step;
+    a.knn_scan_every_step = prm->knn_reference_form ? 2 : (prm->knn_scan_every_step ? 1 : 0);
     a.lr = prm->lr; a.rep_weight = prm->rep_weight; a.threshold = prm->threshold;
     a.rep_radius = prm->rep_radius; a.rep_h = prm->rep_h; a.rep_eps = prm->rep_eps;
     a.coop_timeout_ticks = ctx->coop_timeout_ticks;

@@ -62,6 +62,88 @@ __device__ __forceinline__ void knn_scan2(const f32x4* __restrict__ X, int K, in
     }
 }
 
+// The REFERENCE's neighbour choice, bug for bug (validation only: ifd_opt_params.knn_reference_form; ConvONet/defense/pn_utils.py:72-83):
+//     inner = -2 * matmul(pc^T, pc);  xx = sum(pc ** 2);  dist = xx + inner + xx^T;  topk(-dist, k + 1)[:, :, 1:]
+// in float32 with the accumulation order torch's CPU kernels use for it (verified bit for bit against torch.matmul / torch.sum in
+// tests/test_oracle_golden.py on the host that runs it): dot_ij = fma(z_i, z_j, fma(y_i, y_j, x_i * x_j)), xx_i = (x_i^2 + y_i^2) +
+// z_i^2 with every square rounded, dist_ij = (xx_j + (-2 dot_ij)) + xx_i.  The expanded form carries ~1e-7 of absolute noise, so (i)
+// candidates whose true squared distances differ by less than that swap ranks, and (ii) column 0 of the top-6 - dropped as "self" - is
+// the OTHER point of a pair closer than ~1.5e-4 (dist_ii is itself +-1e-8, not 0): self then stays in as a neighbour with a zero
+// difference vector (loss term, no gradient), and the pair's term is missing.  Brute force over all K points, self included.
+// torch.topk(k = 6) of a 1024-wide row on the CPU is libstdc++'s std::partial_sort over (value, index) pairs with the comparator
+// "x.value > y.value" (ATen/native/cpu/TopKImpl.h: k * 64 <= n): a heap of the six best so far, replaced at the top only by a
+// STRICTLY better candidate, then sort_heap.  Equal values - and the expanded form produces them: dist_ii and the distance to a
+// converged pair partner are both exactly 0.0 or -7.45e-9, two candidates at the sixth place share their f32 distance - come out
+// in the order that heap leaves them in, which is neither index order nor stable.  The heap operations of bits/stl_heap.h are
+// restated here (__adjust_heap / __push_heap / __pop_heap, len <= 6) so that ties fall the same way.
+struct RefHeap {
+    float v[6];      // value = -dist  (comp(a, b) = a.v > b.v)
+    int i[6];
+};
+__device__ __forceinline__ void ref_adjust_heap(RefHeap& h, int hole, int len, float val, int idx) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (h.v[child] > h.v[child - 1]) --child;
+        h.v[hole] = h.v[child]; h.i[hole] = h.i[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h.v[hole] = h.v[child - 1]; h.i[hole] = h.i[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;                    // __push_heap
+    while (hole > top && h.v[parent] > val) {
+        h.v[hole] = h.v[parent]; h.i[hole] = h.i[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h.v[hole] = val; h.i[hole] = idx;
+}
+__device__ __forceinline__ float ref_xx(const f32x4& p);
+__device__ __forceinline__ float rounded_mul(float a, float b) {      // a product that must be ROUNDED before it is added: hipcc
+    float p = a * b;                                                   // contracts a * b + c into an fma wherever it can, also
+    asm volatile("" : "+v"(p));                                        // through __fmul_rn - the empty asm makes the product opaque
+    return p;
+}
+__device__ __forceinline__ float ref_xx(const f32x4& p) { return (rounded_mul(p.x, p.x) + rounded_mul(p.y, p.y)) + rounded_mul(p.z, p.z); }
+__device__ __forceinline__ float ref_neg_dist(const f32x4& xi, float xxi, const f32x4& xj) {
+    const float dot = __builtin_fmaf(xi.z, xj.z, __builtin_fmaf(xi.y, xj.y, rounded_mul(xi.x, xj.x)));
+    return -((ref_xx(xj) + -2.f * dot) + xxi);      // (-2 dot is exact: a contraction of this sum rounds the same)
+}
+// the reference's five neighbours of point i (K >= 6): topk(-dist, 6)[1:]
+__device__ __forceinline__ void knn_ref_point(const f32x4* __restrict__ X, int K, int i, Top5& t) {
+    const f32x4 xi = X[i];
+    const float xxi = ref_xx(xi);
+    RefHeap h;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { h.v[j] = ref_neg_dist(xi, xxi, X[j]); h.i[j] = j; }
+    for (int parent = 2; parent >= 0; --parent) {                      // std::make_heap, len = 6
+        const float v = h.v[parent];
+        const int id = h.i[parent];
+        ref_adjust_heap(h, parent, 6, v, id);
+    }
+    for (int j = 6; j < K; ++j) {                                      // std::__heap_select
+        const float v = ref_neg_dist(xi, xxi, X[j]);
+        if (v > h.v[0]) ref_adjust_heap(h, 0, 6, v, j);                // __pop_heap with the result slot outside the heap
+    }
+    for (int last = 5; last >= 1; --last) {                            // std::__sort_heap
+        const float v = h.v[last];
+        const int id = h.i[last];
+        h.v[last] = h.v[0]; h.i[last] = h.i[0];
+        ref_adjust_heap(h, 0, last, v, id);
+    }
+    t.i0 = h.i[1]; t.i1 = h.i[2]; t.i2 = h.i[3]; t.i3 = h.i[4]; t.i4 = h.i[5];      // column 0 dropped, whatever it is
+    t.d0 = t.d1 = t.d2 = t.d3 = 0.f;
+    t.d4 = fmaxf(-h.v[5], 0.f);
+}
+__device__ __forceinline__ void knn_scan_ref2(const f32x4* __restrict__ X, int K, int pa, int pb, Top5& ta, Top5& tb) {
+    knn_ref_point(X, K, min(pa, K - 1), ta);
+    knn_ref_point(X, K, min(pb, K - 1), tb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Certified neighbour lists: exact 5-NN at O(LIST_M) per point per step.
 //
@@ -855,7 +937,7 @@ struct KnnShared {
 // it together).  Leaves the loss terms in rep_loss_a/b and scatters the neighbour AND centre gradients into F (fixed point).
 template <int S = 1>
 __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const RepAcc F, int K, int pa, int pb,
-                                          int wave, int lane, int step, bool last, bool scan_every_step,
+                                          int wave, int lane, int step, bool last, int scan_every_step /* 1: exact scan, 2: the reference's form */,
                                           const uint16_t* La, const uint16_t* Lb, uint16_t* cloud_lists, KnnPt& ka,
                                           KnnPt& kb, const KnnShared& sh, const RepConst rc, float& rep_loss_a,
                                           float& rep_loss_b, KnnCounters& cn, const CoopView cv = CoopView{nullptr, 0, 0}) {
@@ -866,7 +948,9 @@ __device__ __forceinline__ void knn_phase(const f32x4* __restrict__ X, const Rep
     top5_init(ta);
     top5_init(tb);
     const int ia = min(pa, K - 1), ib = min(pb, K - 1);
-    if (scan_every_step) {
+    if (scan_every_step == 2) {
+        knn_scan_ref2(X, K, pa, pb, ta, tb);
+    } else if (scan_every_step) {
         knn_scan2(X, K, pa, pb, ta, tb);
     } else {
         // A whole-cloud rebuild (new epoch) only when more than IFD_REBUILD_MIN long-lived certificates are about to expire;

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
     for (int step = 0; step < A.steps; ++step) {
         const bool last = step == A.steps - 1;
         if (use_rep)
-            knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb, cloud_lists, ka, kb, ksh,
+            knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step, La, Lb, cloud_lists, ka, kb, ksh,
                       rc, rep_loss_a, rep_loss_b, cn);
 #pragma unroll 1
         for (int g = 0; g < npass; ++g) {

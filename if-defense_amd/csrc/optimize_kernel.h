@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
             TRACE_STAMP(24, "s_waitcnt vmcnt(0)");            // parked state back from scratch
             uint16_t* La = cloud_lists + (size_t)(pa & (MAXK - 1)) * LIST_M;
             uint16_t* Lb = cloud_lists + (size_t)(pb & (MAXK - 1)) * LIST_M;
-            knn_phase<S>(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step != 0, La, Lb,
+            knn_phase<S>(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step, La, Lb,
                          cloud_lists, ka, kb, ksh, rc, rep_loss_a, rep_loss_b, cn, cv);
             const int z2 = opaque_zero();
             park_knnpt(park, z2, PARK_KNN, ka);

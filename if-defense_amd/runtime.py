@@ -212,13 +212,15 @@ class Restorer:
                         return_state: bool = False, return_loss: bool = False, steps: Optional[int] = None,
                         knn_scan_every_step: bool = False, printing: bool = False, split: int = 0,
                         planes_shared: bool = False, rep_radius: float = 0.07, rep_h: float = 0.03, check: bool = True,
-                        precision=None):
+                        precision=None, knn_reference_form: bool = False):
         """optimize_points(opt_points, z, c, rep_weight, iterations) (opt_defense.py:182-239).
 
         Runs ``iterations + 1`` Adam steps (the reference's ``range(iterations + 1)``) unless ``steps``
         is given.  ``loss_batch`` is the reference batch size whose 1/B factor scales both losses
         (default: the number of clouds passed in); an int, or an int32 tensor [B] with one value per cloud.  ``state=(m, v, t0)`` resumes / teacher-forces.
         ``split``: CUs per cloud (ifd_opt_params.split: 0 automatic, 1 / 2 / 4 forced; same results).
+        ``knn_reference_form``: validation only - the reference's neighbour choice bug for bug (ifd_opt_params.knn_reference_form:
+        float32 expanded-form distances, top-6 minus column 0, pn_utils.py:72-83) instead of the exact 5-NN.
         ``precision``: arithmetic of the decoder's dense layers (ifd_opt_params.precision): "f32" / 0 (default), "bf16x6" / 1
         (f32-equivalent on the bf16 matrix core), "bf16x3" / 2 (reduced); None takes the environment's IFD_PRECISION (default f32).
         ``rep_radius`` / ``rep_h``: RepulsionLoss(radius, h) (defense/repulsion_loss.py:9-10; the reference never changes them).
@@ -252,7 +254,7 @@ class Restorer:
         prm = IfdOptParams(C.sizeof(IfdOptParams), n_steps, t0, int(loss_batch or B), int(bool(normalize)),
                            float(lr), float(rep_weight), self.threshold, float(rep_radius), float(rep_h), 1e-12,
                            int(bool(knn_scan_every_step)), int(split or _ENV_SPLIT), int(bool(planes_shared)),
-                           precision_code(precision))
+                           int(bool(knn_reference_form)), precision_code(precision))
         with torch.cuda.device(self.device):
             self._check(self._fn_optimize(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, C.byref(prm),
                                               self._ptr(lb_arr), self._ptr(m), self._ptr(v), self._ptr(loss),

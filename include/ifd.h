@@ -193,6 +193,11 @@ typedef struct ifd_opt_params {
                              split launches on one GPU at the same time (set 1 there). */
     int32_t planes_shared;/* measurement only: != 0 makes every cloud read the planes of cloud 0 (the tap gathers then hit in
                              L2: scripts/ab_planes.py prices the gather traffic this way) */
+    int32_t knn_reference_form; /* validation only (K <= 1024): != 0 ranks the neighbours exactly like the reference - float32 expanded form
+                             |a|^2 + |b|^2 - 2 a.b in torch's accumulation order, top-6, column 0 dropped whatever it is
+                             (ConvONet/defense/pn_utils.py:72-83), by brute force every step - instead of the exact 5-NN of direct
+                             differences.  The reference's form swaps candidates closer than its ~1e-7 noise and, for pairs of points
+                             closer than ~1.5e-4, keeps "self" as a neighbour and drops the pair's term; the product path does not. */
     int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers in the persistent kernel (K <= 1024):
                              0 = f32 MFMA (v_mfma_f32_16x16x4_f32: bit-equal to an fmaf chain) - the default;
                              1 = "bf16x6": both operands split exactly into three bf16 pieces, six piece products on the bf16

@@ -202,3 +202,84 @@ def test_trained_like_oracle_trajectory():
         assert np.abs(x1.numpy() - f[f"traj{t}_x_next"]).max() < 2e-6
     out = O.optimize_points(w, torch.from_numpy(f["init_points"]), planes, rep_weight=500.0, iterations=9, normalize=False)
     assert np.linalg.norm(out.numpy() - f["traj9_x_next"], axis=-1).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference's kNN, restated to the bit (what csrc/knn_device.h knn_ref_point runs under ifd_opt_params.knn_reference_form)
+# ------------------------------------------------------------------------------------------------
+def _ref_topk6_restated(neg_dist_row):
+    """std::partial_sort of libstdc++ (bits/stl_heap.h) over (value, index) with comp(a, b) = a.value > b.value: what torch.topk(k = 6)
+    runs on a CPU row of 1024 (ATen/native/cpu/TopKImpl.h, k * 64 <= n) - including what it does with EQUAL values."""
+    v = [float(x) for x in neg_dist_row[:6]]
+    ix = list(range(6))
+
+    def adjust(hole, length, val, idx):
+        top, child = hole, hole
+        while child < (length - 1) // 2:
+            child = 2 * (child + 1)
+            if v[child] > v[child - 1]:
+                child -= 1
+            v[hole], ix[hole] = v[child], ix[child]
+            hole = child
+        if length % 2 == 0 and child == (length - 2) // 2:
+            child = 2 * (child + 1)
+            v[hole], ix[hole] = v[child - 1], ix[child - 1]
+            hole = child - 1
+        parent = (hole - 1) // 2
+        while hole > top and v[parent] > val:
+            v[hole], ix[hole] = v[parent], ix[parent]
+            hole = parent
+            parent = (hole - 1) // 2
+        v[hole], ix[hole] = val, idx
+
+    for parent in (2, 1, 0):
+        adjust(parent, 6, v[parent], ix[parent])
+    for j in range(6, len(neg_dist_row)):
+        x = float(neg_dist_row[j])
+        if x > v[0]:
+            adjust(0, 6, x, j)
+    for last in range(5, 0, -1):
+        val, idx = v[last], ix[last]
+        v[last], ix[last] = v[0], ix[0]
+        adjust(0, last, val, idx)
+    return ix
+
+
+def test_reference_knn_restated_to_the_bit():
+    """knn_point (pn_utils.py:72-83) on this host: (i) the float32 accumulation order of matmul / sum the kernel restates, (ii) the
+    tie behaviour of topk - on the converged trained-like fixture (where pairs of points make dist_ii and dist_ij tie at exactly 0)
+    and on rows of integers (many ties)."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convonet_golden_trained_long.npz"))
+    pc = torch.from_numpy(f["traj499_x"])
+    inner = -2.0 * torch.matmul(pc, pc.transpose(2, 1))
+    xx = torch.sum(pc.transpose(2, 1) ** 2, dim=1, keepdim=True)
+    dist = xx + inner + xx.transpose(2, 1)
+    x = pc.numpy()
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    xi, xj = x[:, :, None, :], x[:, None, :, :]
+    dot = fma(xi[..., 2], xj[..., 2], fma(xi[..., 1], xj[..., 1], xi[..., 0] * xj[..., 0]))
+    sq = [x[..., k] * x[..., k] for k in range(3)]
+    xxn = (sq[0] + sq[1]) + sq[2]
+    mine = (xxn[:, None, :] + np.float32(-2.0) * dot) + xxn[:, :, None]
+    assert np.array_equal(mine, dist.numpy())                                 # (i)
+    _, top = (-dist).topk(6, dim=-1)
+    nd = (-dist).numpy()
+    ties = 0
+    for b in range(nd.shape[0]):
+        for i in range(0, nd.shape[1], 1):
+            row = nd[b, i]
+            s = np.sort(row)[::-1][:7]
+            if (s[:-1] == s[1:]).any():                                        # rows with a tie among the best seven: all of them
+                ties += 1
+                assert _ref_topk6_restated(row) == top[b, i].tolist(), (b, i)
+            elif i % 16 == 0:
+                assert _ref_topk6_restated(row) == top[b, i].tolist(), (b, i)
+    assert ties >= 10, ties                                                    # (measured: 26 rows of 8192 tie at Adam t = 500)
+    g = torch.Generator().manual_seed(3)
+    v = torch.randint(0, 9, (48, 1024), generator=g).float()
+    _, top = v.topk(6, dim=-1)
+    for r in range(48):
+        assert _ref_topk6_restated(v[r].numpy()) == top[r].tolist(), r
