@@ -97,11 +97,14 @@ def gather_shards(local: torch.Tensor, n_total: int, per: int) -> torch.Tensor:
     if not dist.is_initialized():
         return local[:n_total]
     world = dist.get_world_size()
-    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # (gloo moves host memory: device shards - several processes sharing ONE GPU in tests/test_gpu_two_processes.py - go through the host)
+    via_host = dist.get_backend() != "nccl" and local.is_cuda
+    src = local.cpu() if via_host else local
+    pad = torch.zeros((per,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[:src.shape[0]] = src
+    out = torch.empty((world * per,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     dist.all_gather_into_tensor(out, pad)          # RCCL ncclAllGather over xGMI (one call, ~30 MB for 2468 clouds)
-    return out[:n_total]
+    return (out.to(local.device) if via_host else out)[:n_total]
 
 
 def defend_sharded(defend: Callable[[np.ndarray, int, int], torch.Tensor], pc: np.ndarray, device=None) -> torch.Tensor:
