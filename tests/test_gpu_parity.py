@@ -809,6 +809,22 @@ def _attribute_separations(r, MO, w, cond, loss_batch, hx, hg, ox, og, tag, onse
 
     np.testing.assert_allclose(_oracle_grad(MO, w, ox[0], cond, loss_batch), og[0], rtol=0, atol=1e-6 * np.abs(og[0]).max())
     reasons, unexplained = {}, []
+    def gradient_cause(b, i, t):
+        """B / R at step t for point (b, i): the implementations' gradients differ at IDENTICAL positions (None if they do not)."""
+        g1, g2, hip_idx, ref_idx = at_step(t)
+        noise = g_noise * np.abs(og[t, b]).max()
+        d_impl = np.abs(hg[t, b, i] - g1[b, i]).max()
+        d_idx = np.abs(hg[t, b, i] - g2[b, i]).max()
+        if d_impl <= noise:
+            return None
+        if d_idx <= noise:
+            return "B at step %d (gradients %.1e of max apart, %.1e with the build's 5-NN sets in the oracle)" % (t, d_impl / noise * g_noise, d_idx / noise * g_noise)
+        cond_b = {k: v[b:b + 1] for k, v in cond.items()} if isinstance(cond, dict) else cond[b:b + 1]
+        jumps = _oracle_kink_jumps(MO, w, hx[t, b, i], cond_b, loss_batch)
+        miss = np.abs(jumps - (hg[t, b, i] - g1[b, i])[None]).max(-1).min()
+        return "R at step %d (gradients %.1e of max apart; an oracle jump under a nudge of <= 512 ulps within %.1e)" % (
+            t, d_impl / noise * g_noise, miss / noise * g_noise) if miss <= 3.0 * noise else None
+
     for b, i in todo:
         t = int(onset[b, i])
         g1, g2, hip_idx, ref_idx = at_step(t)
@@ -834,8 +850,13 @@ def _attribute_separations(r, MO, w, cond, loss_batch, hx, hg, ox, og, tag, onse
                     d_impl / noise * g_noise, d_sens / noise * g_noise, sep[t, b].max())
         elif d_impl <= noise:
             hist = max(np.abs(og[:t + 1, b, i, a]).max(), np.abs(hg[:t + 1, b, i, a]).max())
-            if hist <= 10.0 * noise:
-                why = "A: all gradients agree to %.1e; |g| <= %.1e of max over steps 0..%d" % (max(d_impl, d_sens) / noise * g_noise, hist / noise * g_noise, t)
+            # Adam's first steps move a coordinate by ~lr * sign-like(m / sqrt(v)): a RELATIVE perturbation delta of the coordinate's
+            # gradient moves x by ~lr * delta per step.  Either |g| is inside the noise band outright, or the agreed noise, relative
+            # to the coordinate's own |g|, accounts for at least half of the separation seen at the onset.
+            amplified = 1e-3 * max(d_impl, d_sens) / max(hist, 1e-30) * (t + 1)
+            if hist <= 10.0 * noise or amplified >= 0.5 * sep[t + 1, b, i]:
+                why = "A: all gradients agree to %.1e; |g| <= %.1e of max over steps 0..%d (lr x relative noise x steps = %.1e against a separation of %.1e)" % (
+                    max(d_impl, d_sens) / noise * g_noise, hist / noise * g_noise, t, amplified, sep[t + 1, b, i])
         else:
             cond_b = {k: v[b:b + 1] for k, v in cond.items()} if isinstance(cond, dict) else cond[b:b + 1]
             jumps = _oracle_kink_jumps(MO, w, hx[t, b, i], cond_b, loss_batch)
@@ -845,7 +866,20 @@ def _attribute_separations(r, MO, w, cond, loss_batch, hx, hg, ox, og, tag, onse
             if miss <= 3.0 * noise:
                 why = "R: same positions and neighbour sets, gradients %.1e apart (of max); the oracle's own occupancy gradient makes that jump (to %.1e) under a nudge of <= 512 ulps" % (
                     d_impl / noise * g_noise, miss / noise * g_noise)
+        if why is None and d_impl <= noise:
+            # The gradients agree at the onset step - but Adam's first steps move every coordinate by ~lr sign(g) whatever |g| is, so a
+            # difference between the implementations' gradients at an EARLIER step (positions still identical) only surfaces later,
+            # through the moments.  Look back for it.
+            for s_ in range(t - 1, -1, -1):
+                if np.abs(hx[s_, b, i] - ox[s_, b, i]).max() <= 1e-7:
+                    cause = gradient_cause(b, i, s_)
+                    if cause is not None:
+                        why = cause[0] + ": latent - " + cause + "; it reaches the positions through Adam's moments at step %d" % t
+                        break
         if why is None:
+            print("  %s: UNEXPLAINED cloud %d point %d coordinate %d, onset step %d: x build %s oracle %s; g build %s oracle %s (max |g| of the cloud %.3e)" % (
+                tag, b, i, a, t, hx[:t + 2, b, i, a].tolist(), ox[:t + 2, b, i, a].tolist(), hg[:t + 1, b, i, a].tolist(), og[:t + 1, b, i, a].tolist(),
+                np.abs(og[t, b]).max()))
             unexplained.append((int(b), int(i), t, a, "d_impl %.1e d_idx %.1e d_sens %.1e (of max)" % (
                 d_impl / noise * g_noise, d_idx / noise * g_noise, d_sens / noise * g_noise)))
         else:
@@ -1130,6 +1164,33 @@ def test_full_size_properties(restorer):
     lo = I.defend_point_cloud(restorer, clouds[:1234], args, cloud_index_base=0, total_clouds=2468)
     hi = I.defend_point_cloud(restorer, clouds[1234:], args, cloud_index_base=1234, total_clouds=2468)
     assert np.array_equal(np.concatenate([lo, hi]), full)
+    # Parity INSIDE the full-size launch (round-4 verdict, item 9): clouds taken out of a late whole round of the 2468-cloud launch
+    # (clouds 2048 ... 2303 are its ninth round of 256) and out of the 164-wide tail round (2304 ... 2467, whose reference batch has
+    # 164 members: another 1 / B) come out bit-identical when they are restored as a batch of four on their own ...
+    for base in (2050, 2460):
+        small = I.defend_point_cloud(restorer, clouds[base:base + 4], args, cloud_index_base=base, total_clouds=2468)
+        assert np.array_equal(small, full[base:base + 4]), base
+    # ... and two of each are held against the oracle over 20 free-running steps with the attribution protocol (every separating
+    # point explained; the count beyond 1e-3 inside the oracle's own 1-ulp floor + 5, like the configuration tests)
+    from oracle import convonet_oracle as O
+    ow = O.to_torch(O.make_random_weights(0))
+    x = torch.from_numpy(clouds).cuda()
+    for base, B in ((2050, 192), (2460, 164)):
+        xs = x[base:base + 2]
+        prep = restorer.prepare(xs, restorer.sor(xs), seed=1234, cloud_index_base=base)
+        planes = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        T = 20
+        hx, hg, last = _hip_trace(restorer, prep["init"], planes, T, B)
+        pd = I.planes_from_channel_last(planes.cpu())
+        ox, og = _oracle_trace(O, ow, prep["init"].cpu(), pd, T, B)
+        _attribute_separations(restorer, O, ow, pd, B, hx, hg, ox, og, "clouds %d, %d of the full-size launch, 20 steps" % (base, base + 1))
+        n_off = int((np.linalg.norm(hx[-1] - ox[-1], axis=-1) > 1e-3).sum())
+        floor = _ulp_floor(O, ow, prep["init"].cpu(),
+                           lambda q: O.optimize_points(ow, q, pd, rep_weight=500.0, iterations=T - 1, loss_batch=B, normalize=False).numpy(),
+                           T - 1, B, ox[-1])
+        print("clouds %d, %d of the full-size launch: points beyond 1e-3 after 20 steps: build vs oracle %d, oracle vs its 1-ulp-perturbed runs %s"
+              % (base, base + 1, n_off, floor))
+        assert n_off <= max(floor) + 5, (base, n_off, floor)
 
 
 # ------------------------------------------------------------------------------------------------
