@@ -205,6 +205,21 @@ def _cpu_worker(job):
     return (time.perf_counter() - t0) / steps
 
 
+def _cpu_worker_cold(job):
+    """(no warm-up step: one step of 192 clouds at one thread per core takes half a minute - start-up costs vanish in it)"""
+    seed, n, steps, threads = job
+    torch.set_num_threads(threads)
+    from oracle import convonet_oracle as O
+    w = O.to_torch(O.make_random_weights(0))
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(n, K_POINTS, 3, generator=g)
+    init = 0.4 * v / v.norm(dim=-1, keepdim=True) + 0.01 * torch.randn(n, K_POINTS, 3, generator=g)
+    planes = {k: 0.5 * torch.randn(n, 32, 64, 64, generator=g) for k in ("xz", "xy", "yz")}
+    t0 = time.perf_counter()
+    O.optimize_points(w, init, planes, rep_weight=500.0, iterations=steps - 1, normalize=False)
+    return (time.perf_counter() - t0) / steps
+
+
 def cpu_baseline_saturating(base, budget_s=20.0):
     """Two host-SATURATING figures next to the 16-thread one (round-4 verdict): (i) floor(cores / 16) concurrent 16-thread workers on
     disjoint 16-cloud batches, (ii) the reference's own batch of 192 clouds in ONE process at os.cpu_count() threads (BASELINE.md
@@ -234,10 +249,10 @@ def cpu_baseline_saturating(base, budget_s=20.0):
         out["workers_x16_threads"] = {"error": str(e)[:200]}
     try:
         t0 = time.perf_counter()
-        per = _cpu_worker((7, 192, 1, cores))
+        per = _cpu_worker_cold((7, 192, 1, cores))
         out["batch192_all_threads"] = {
             "value": round(192 / (per * (ITERATIONS + 1)), 4), "unit": "clouds/s", "cores": cores,
-            "sample": "ONE process, torch.set_num_threads(%d), the reference's batch of 192 clouds: 1 warm-up + 1 timed Adam step (%.2f s), "
+            "sample": "ONE process, torch.set_num_threads(%d), the reference's batch of 192 clouds: 1 timed Adam step (%.2f s), "
                       "optimiser loop only, scaled to %d steps (%.1f s in all)" % (cores, per, ITERATIONS + 1, time.perf_counter() - t0)}
     except Exception as e:      # noqa: BLE001
         out["batch192_all_threads"] = {"error": str(e)[:200]}
@@ -579,12 +594,12 @@ def main():
             # the same passes as a stream of files (what a directory of .npz files through the CLI does): five passes, driver-timed
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in I.defend_stream(r, [x] * 5, args, bases=[lo] * 5, totals=[total] * 5, overlap=True):
+            for _ in I.defend_stream(r, [x] * 8, args, bases=[lo] * 8, totals=[total] * 8, overlap=True):
                 pass
             torch.cuda.synchronize()
-            dt1 = (time.perf_counter() - t1) / 5
+            dt1 = (time.perf_counter() - t1) / 8
             streamed = {"value": round(total / dt1, 2), "unit": "clouds/s", "ms_per_file": round(dt1 * 1e3, 2),
-                        "what": "the same workload driven as a stream of 5 files: pre-processing of file n+1 on a second HIP stream under "
+                        "what": "the same workload driven as a stream of 8 files: pre-processing of file n+1 on a second HIP stream under "
                                 "file n's last optimiser round (a directory input of the CLI); the first file has nothing to hide under"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(my_clouds, onet=onet, full_run_clouds=0 if onet else 4)
