@@ -5,7 +5,8 @@
 
 namespace ifd {
 
-constexpr size_t OPT_LDS_BF = (size_t)BF_IMG_BYTES + MAXK * 16 * 3 + 16 + MAXK * 12 + 128 * 4;      // 156,704 B (the moments are in global memory)
+// 158,752 B (the moments are in global memory; the last 2 KB: one 256-byte landing strip per wave for the tap prefetches of tile_bf.h)
+constexpr size_t OPT_LDS_BF = (size_t)BF_IMG_BYTES + MAXK * 16 * 3 + 16 + MAXK * 12 + 128 * 4 + 8 * 256;
 static_assert(OPT_LDS_BF <= 160 * 1024, "LDS budget");
 
 hipError_t configure_optimize_bf_kernels() {

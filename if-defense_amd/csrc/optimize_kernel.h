@@ -1244,14 +1244,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
                                             A.threshold, inv_lb, want_loss, bce, dx, tr2);
                 else
                     decoder_tile3_bf<MODE_OPT, PREC>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
-                                                     A.threshold, want_loss, bce, dx, tr2);
+                                                     A.threshold, want_loss, bce, dx, scratch + 128 + 64 * wave, tr2);
 #else
                 if (PREC == 0)
                     decoder_tile3<MODE_OPT>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
                                             A.threshold, inv_lb, want_loss, bce, dx);
                 else
                     decoder_tile3_bf<MODE_OPT, PREC>(W, plr, PIX[tpa], PIX[tpb], Xf[4 * tpa], Xf[4 * tpb], lane, dc,
-                                                     A.threshold, want_loss, bce, dx);
+                                                     A.threshold, want_loss, bce, dx, scratch + 128 + 64 * wave);
 #endif
                 if (lane < 16) {
                     if (ia < K) G[tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};

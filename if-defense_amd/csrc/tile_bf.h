@@ -255,7 +255,7 @@ template <int MODE, int PREC>
 __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, __amdgpu_buffer_rsrc_t planes,
                                                  const f32x4 ppa, const f32x4 ppb, float xqa, float xqb, int lane,
                                                  const DecConst dc, float thr, bool want_loss, float (&bce)[2], float (&dx)[2][3],
-                                                 [[maybe_unused]] unsigned long long* tr = nullptr) {
+                                                 [[maybe_unused]] float* pf_strip, [[maybe_unused]] unsigned long long* tr = nullptr) {
     T2(0);                                       // (-DIFD_TRACE2 stamps: decoder_tile3's slot map, scripts/tile_trace.py)
     BF_PRIO(IFD_BF_PRIO_EDGE);
     const lds_u8* Wb = (const lds_u8*)Wg;
@@ -315,6 +315,26 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
                 tap[t][1][mt] = __builtin_bit_cast(f32x4, t1);
                 tap[t][2][mt] = __builtin_bit_cast(f32x4, t2);
                 tap[t][3][mt] = __builtin_bit_cast(f32x4, t3);
+            }
+        }
+    };
+    // L2 prefetch of the tile's 384 tap lines (3 planes x 2 rows x [32 points x 2 columns]) with six LDS-DMA loads - one dword per lane
+    // and line, no destination registers (buffer_load ... lds into this wave's 256-byte landing strip, never read): the backward
+    // pass re-gathers the taps ~15 k cycles after the forward gather fetched them, by which time they have left the XCD's L2
+    // (its 4 MB turn over in ~7 us under 32 CUs' gathers).  Lane (n, q) takes point n of sub-tile q & 1, column q >> 1.
+#ifndef IFD_BF_PREFETCH
+#define IFD_BF_PREFETCH 0      // measured: +11 % (bf16x6) / +27 % (bf16x3) - the kernel is bound by the tap TRAFFIC, not by its latency (profiles/r05_ab_bf_prefetch.txt)
+#endif
+    auto prefetch_taps = [&]() {
+        const bool t1 = (q & 1) != 0;
+#pragma unroll
+        for (int P = 0; P < 3; ++P) {
+            const int a0 = AX0[P], a1 = AX1[P];
+            const int cx = (t1 ? geo[1].cell[a0] : geo[0].cell[a0]) + (q >> 1), cy = t1 ? geo[1].cell[a1] : geo[0].cell[a1];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int off = ((cy + h) * RES + cx) * (CH * 4) + P * PLANE_FLOATS * 4;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(planes, (__attribute__((address_space(3))) void*)pf_strip, 4, off, 0, 0, 0);
             }
         }
     };
@@ -475,6 +495,7 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     T2(35);
     BF_PRIO(IFD_BF_PRIO_MLP);
 
+    if (IFD_BF_PREFETCH & 1) prefetch_taps();      // (for the re-gather behind the backward MLP; off: see IFD_BF_PREFETCH)
     // ---- backward (A holds fc_1[4]^T) --------------------------------------------------------------------------------------
     Acc2 dcc[2] = {acc_zero(), acc_zero()};
 #pragma unroll
