@@ -450,8 +450,15 @@ def main():
     ap.add_argument("--workload", choices=("convonet-opt", "onet-opt"), default="convonet-opt",
                     help="convonet-opt = the BASELINE metric (default); onet-opt = the ONet-Opt decoder variant "
                          "(BASELINE config #1 model, SURVEY N4) at 500 iterations - an extra line, not the headline")
+    ap.add_argument("--profile-precision", choices=("f32", "bf16x6", "bf16x3"), default="f32",
+                    help="PROFILING ONLY (scripts/pmc_bench.sh): run the timed passes in a split-precision mode; the line is then labelled "
+                         "as such in metric / dtype / config.arith and is not the BASELINE metric")
     a = ap.parse_args()
     a.no_overlap = not a.streamed
+    # the headline is f32 whatever the environment says (IFD_PRECISION is runtime.py's measurement hook)
+    os.environ.pop("IFD_PRECISION", None)
+    if a.profile_precision != "f32":
+        os.environ["IFD_PRECISION"] = a.profile_precision
     onet = a.workload == "onet-opt"
     if onet and a.clouds == N_CLOUDS:
         a.clouds = 256                                                  # one cloud per CU; ~3 s per step
@@ -589,6 +596,14 @@ def main():
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
             "gather_ms": round(sum(g0.elapsed_time(g1) for g0, g1 in gev) / max(1, len(gev)), 3),
         }
+        if a.profile_precision != "f32":
+            # a profiling run of the opt-in split-precision mode: labelled so that it cannot be read as the BASELINE metric
+            res["metric"] += " [PROFILING RUN, decoder layers %s - not the headline]" % a.profile_precision
+            res["dtype"] = "%s (%s)" % (a.profile_precision, "f32-equivalent split" if a.profile_precision == "bf16x6" else "REDUCED precision")
+            res["config"]["arith"] = ("decoder dense layers as %s bf16 products on v_mfma_f32_16x16x32_bf16 (ifd_opt_params.precision, "
+                                      "csrc/tile_bf.h); everything else f32" % ("six" if a.profile_precision == "bf16x6" else "three"))
+            res["roofline"]["note"] = "achieved is in f32-EQUIVALENT FLOP against the f32-MFMA peak; the matrix core executes %dx as many bf16 FLOP" % \
+                (6 if a.profile_precision == "bf16x6" else 3)
         streamed = None
         if world == 1 and not onet and not a.no_extras and a.no_overlap:
             # the same passes as a stream of files (what a directory of .npz files through the CLI does): five passes, driver-timed

@@ -2,6 +2,8 @@
 // (v_pk_mul_f32 / v_pk_fma_f32 run two passes through the vector ALU) with one wait state and counts an s_waitcnt that happens to
 // stand between them as that state.  This probe issues the pair from inline asm (nothing padded) with  (a) nothing,  (b) an
 // s_waitcnt whose condition already holds,  (c) s_nop 0  in between, and counts wrong results.
+// RESULT (MI355X): 0 wrong results in every form - the hypothesis is WRONG; the errors it was meant to explain come from packed f32 beside
+// a bf16-MFMA partner wave (scripts/pk_mfma_coexec.hip).
 //   hipcc --offload-arch=gfx950 -O3 pk_waitcnt_hazard.hip -o pk_waitcnt_hazard && ./pk_waitcnt_hazard
 #include <hip/hip_runtime.h>
 #include <cstdio>

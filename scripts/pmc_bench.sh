@@ -6,7 +6,7 @@ TAG=${1:-x}
 CLOUDS=${2:-2468}
 R=$(pwd)
 OUT=$R/gpurun_out/pmc_bench_$TAG
-CMD="python $R/bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline --no-overlap"
+CMD="python $R/bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline ${PMC_BENCH_ARGS:-}"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0

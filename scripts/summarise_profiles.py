@@ -47,7 +47,7 @@ def source_sha():
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("optimize.hip", "knn_device.h", "ifd_device.h"):
+    for f in ("optimize.hip", "optimize_kernel.h", "knn_device.h", "ifd_device.h"):
         h.update(open(os.path.join(root, "if-defense_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

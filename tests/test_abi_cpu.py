@@ -231,23 +231,24 @@ def test_split_cloud_arrivals_are_preceded_by_a_vmcnt0_wait(lib, tmp_path):
     assert len(found) == 6, "optimize_kernel<8, 2 | 4, 0 | 1 | 2> not all found in libifd.so: %s" % sorted(found)
 
 
-def test_no_packed_f32_result_is_read_across_a_bare_waitcnt(lib, tmp_path):
-    """Round 5: hipcc (ROCm 7.2) pads a packed-f32 producer -> dependent vector consumer pair with one wait state and counts an
-    s_waitcnt that stands between the two as that state; gfx950 spends no cycle on a wait whose condition already holds, and the
-    consumer then reads the old register (scripts/pk_waitcnt_hazard.hip; it made ~1 % of the split-precision tile's first
-    sub-tiles wrong, run to run).  No optimiser or encoder kernel of the shipped library may contain the pattern where the wait
-    can already be satisfied; the known remaining sites wait for a spill reload or scalar load issued just before (listed)."""
-    import importlib.util
+def test_split_precision_kernels_contain_no_packed_f32_instruction(lib, tmp_path):
+    """Round 5: on gfx950 a packed-f32 vector instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) whose dependent consumer does
+    not issue back to back occasionally delivers a wrong result while the OTHER wave of its SIMD streams bf16 MFMAs (0 wrong of 5e9
+    with an idle or f32-MFMA partner, 48 - 288 with a bf16-MFMA partner: scripts/pk_mfma_coexec.hip, profiles/r05_pk_mfma_coexec.txt;
+    it made ~1 % of the split-precision tile's sub-tiles wrong, run to run).  The split-precision optimiser kernels are the only ones
+    that issue bf16 MFMAs, and they are built without packed f32 (build.py FILE_FLAGS: -fno-slp-vectorize, scalar sampling code in
+    tile_bf.h): checked in the shipped ISA.  (An earlier hypothesis - a satisfied s_waitcnt counted as the pair's wait state - was
+    disproved by scripts/pk_waitcnt_hazard.hip: 0 wrong in every form.)"""
     import ifdefense_amd as I
-    spec = importlib.util.spec_from_file_location("asm_pk_hazard", os.path.join(ROOT, "scripts", "asm_pk_hazard.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    bad = {}
-    n_kernels = 0
+    found = {}
     for txt in _disassemblies(I.LIB_PATH, tmp_path):
-        n_kernels += len(re.findall(r"^[0-9a-f]+ <_ZN3ifd", txt, flags=re.M))
-        bad.update(mod.scan(txt.split("\n")))
-    assert n_kernels >= 30, n_kernels
-    allowed = ("encode_points_kernel",)       # the thread-per-point encoder kept for validation (IFD_ENC_VALU=1): waits on scalar loads
-    bad = {k: v for k, v in bad.items() if not any(a in k for a in allowed)}
-    assert not bad, {k: v[:2] for k, v in bad.items()}
+        for sym in sorted(set(re.findall(r"<_ZN3ifd15(optimize_kernelILi8ELi[124]ELi[012]E)", txt))):
+            body = txt[txt.index("<_ZN3ifd15" + sym):]
+            body = body[:body.index("s_endpgm")]
+            found[sym] = (len(re.findall(r"\bv_pk_(?:mul|fma|add)_f32\b", body)), len(re.findall(r"\bv_mfma_f32_16x16x32_bf16\b", body)))
+    assert len(found) == 9, sorted(found)
+    for sym, (n_pk, n_bf) in found.items():
+        if sym.endswith("Li0E"):
+            assert n_bf == 0 and n_pk > 0, (sym, n_pk, n_bf)         # the f32 kernels: packed f32 is fine beside f32 MFMAs (and used)
+        else:
+            assert n_bf > 100 and n_pk == 0, (sym, n_pk, n_bf)
