@@ -322,8 +322,11 @@ typedef struct ifd_mesh_params {
 int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_params* prm, float* points,
                          int32_t* n_triangles, float* grid, float* triangles, void* stream);
 
-/* The marching-cubes polygonisation table this library generates at start-up (host memory: tri [256*16] edge
- * triples terminated by -1, ntri [256]).  Corner / edge numbering as in libmcubes (marchingcubes.h:44-64). */
+/* The marching-cubes polygonisation table this library uses (host memory: tri [256*16] edge triples terminated by -1,
+ * ntri [256]): csrc/mc_table_data.h, a committed constant table that records what the REFERENCE's compiled libmcubes emits for
+ * each of the 256 single-cube sign configurations - edge triples in its order and winding - obtained by running that library
+ * (scripts/probe_mc_table.py; fixture tests/golden/mc_table_ref.npz; it is the classic Lorensen-Cline table in libmcubes'
+ * numbering).  Nothing is generated at start-up.  Corner / edge numbering as in libmcubes (marchingcubes.h:44-64). */
 int ifd_mc_table(int8_t* tri, uint8_t* ntri);
 
 #ifdef __cplusplus
