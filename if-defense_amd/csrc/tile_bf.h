@@ -261,7 +261,11 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     const lds_u8* Wb = (const lds_u8*)Wg;
     const int n = lane & 15, q = lane >> 4;
     int lane_off = lane * BF_ENTRY_BYTES;
+#ifdef IFD_BF_TIMING_TR_LINEAR                   // timing experiment, WRONG results: the transposed reads without their bank conflicts
+    int lane_off_t = lane * 8;
+#else
     int lane_off_t = ((lane & 3) * 16 + 4 * q + ((lane >> 2) & 3)) * BF_ENTRY_BYTES;
+#endif
     int q4 = 4 * q;
     asm volatile("" : "+v"(lane_off), "+v"(lane_off_t), "+v"(q4));
     constexpr int AX0[3] = {0, 0, 1}, AX1[3] = {2, 1, 2};   // xz, xy, yz (common.py:243-248)

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void k16(const float* __res
         for (int e = 0; e < 8; ++e) sum += x[t][e];
     yout[blockIdx.x * THREADS + threadIdx.x] = sum;
     msk[blockIdx.x * THREADS + threadIdx.x] = macc;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) atomicMax(cyc, t1 - t0);        // the LONGEST wave: the older wave of a SIMD finishes early
 }
 
 // 32-point tiles on 32x32x2: lane (n = lane & 31, half = lane >> 5) holds 16 channels of point n; k-step s takes register s
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void k32(const float* __res
         for (int e = 0; e < 16; ++e) sum += x[t][e];
     yout[blockIdx.x * THREADS + threadIdx.x] = sum;
     msk[blockIdx.x * THREADS + threadIdx.x] = macc;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) atomicMax(cyc, t1 - t0);        // the LONGEST wave: the older wave of a SIMD finishes early
 }
 
 template <typename K>
@@ -120,6 +120,7 @@ void run(const char* name, K kern, int threads, int pts_per_wave, const float* d
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(dc, 0, 8);
         hipEventRecord(e0);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), shm, 0, dimg, dx, dy, dc, dm, iters);
         hipEventRecord(e1);
