@@ -420,7 +420,7 @@ def extras(dev):
                             "roofline_frac": round(flop_m / dtm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                             "what": "ifd_onet_mesh_sample, 64 clouds, 32 -> 128 MISE grid, iso-surface at the field's median; "
                                     "roofline_frac = decoder FLOPs of the evaluated grid points / WHOLE-path time / f32-MFMA peak "
-                                    "(onet_grid_eval_kernel alone: profiles/r04_onet_mesh_kernel_stats.txt)"}
+                                    "(onet_grid_eval_kernel alone: profiles/r05_onet_mesh_kernel_stats.txt)"}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["onet"] = {"error": str(e)[:200]}

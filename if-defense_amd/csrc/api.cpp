@@ -1,8 +1,8 @@
 // C ABI of libifd.so (see include/ifd.h).  Host-side only: context, weight re-packing, argument validation and kernel
 // launches.  Never throws, never exits.  Every call runs on the context's own device (DeviceGuard).  Calls only enqueue
 // work on the caller's stream, with these exceptions, which block the host: ifd_create / ifd_onet_create / ifd_destroy
-// (allocation, upload), ifd_get_counters (device-to-host copy), ifd_onet_mesh_sample (one stream synchronisation per MISE
-// round: the host reads how many grid points to evaluate), and any call that needs MORE context workspace than every
+// (allocation, upload), ifd_get_counters (device-to-host copy), ifd_onet_mesh_sample (the MISE loop is driven from the device; the
+// host waits on an event per round - one round BEHIND what it has enqueued - only to learn when the queues have run empty), and any call that needs MORE context workspace than every
 // earlier call on that context (the old buffer is freed after a device synchronisation; steady-state calls never do).
 #include "../../include/ifd.h"
 
@@ -116,6 +116,9 @@ struct ifd_ctx {
     void* ws_mesh = nullptr;       // ONet-Mesh scratch (MISE arrays, triangle soup)
     unsigned long long mesh_points = 0, mesh_rounds = 0;   // grid points evaluated / MISE rounds of the last mesh call
     size_t ws_mesh_bytes = 0;
+    int* h_mesh_counts = nullptr;  // pinned: the queue lengths of the last two MISE rounds (ifd_onet_mesh_sample reads them one round late)
+    size_t h_mesh_counts_n = 0;    // ints per slot
+    hipEvent_t mesh_ev[2] = {nullptr, nullptr};
     // read from the environment once, at creation (read_opt_env): bound of the cross-CU waits of split clouds, test hook
     unsigned int coop_timeout_ticks = 3000000000u;
     int test_drop_member = -1;
@@ -541,6 +544,8 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->d_onet_img) (void)hipFree(ctx->d_onet_img);
     if (ctx->d_onet_small) (void)hipFree(ctx->d_onet_small);
     if (ctx->ws_mesh) (void)hipFree(ctx->ws_mesh);
+    if (ctx->h_mesh_counts) (void)hipHostFree(ctx->h_mesh_counts);
+    for (hipEvent_t ev : ctx->mesh_ev) if (ev) (void)hipEventDestroy(ev);
     delete ctx;
 }
 
@@ -748,6 +753,10 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     ifd_ctx* ctx = new (std::nothrow) ifd_ctx();
     if (!ctx) { g_create_error = "ifd_onet_create: out of host memory"; return nullptr; }
     ctx->device = device;
+    {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
+    }
     ctx->model = IFD_MODEL_ONET;
     ctx->w.assign(weights_host, weights_host + n_weights);
     const float* w = ctx->w.data();
@@ -936,9 +945,20 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
     const size_t fit = ((size_t)6 << 30) / per;                 // ~6 GB of scratch per pass
     const int chunk = fit < 1 ? 1 : fit > (size_t)B ? B : (int)fit;
     // layout: arrays are [chunk][stride] each (struct-of-arrays), plus count / ntri / ab folded separately
-    const size_t total = per * chunk + al((size_t)chunk * 4) * 2;
+    const size_t total = per * chunk + al((size_t)chunk * 4) * 3 + al((size_t)(chunk + 1) * 4);
     hipError_t e = ensure_buf(&ctx->ws_mesh, &ctx->ws_mesh_bytes, total);
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_mesh_sample workspace", e);
+    if (ctx->h_mesh_counts_n < (size_t)chunk) {          // pinned landing slots of the queue lengths + their events (kept by the context)
+        if (ctx->h_mesh_counts) (void)hipHostFree(ctx->h_mesh_counts);
+        ctx->h_mesh_counts = nullptr;
+        ctx->h_mesh_counts_n = 0;
+        e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mesh_counts), (size_t)2 * chunk * sizeof(int), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_onet_mesh_sample pinned counts", e);
+        ctx->h_mesh_counts_n = (size_t)chunk;
+    }
+    for (hipEvent_t& ev : ctx->mesh_ev)
+        if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess)
+            return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample events", e);
     char* base = static_cast<char*>(ctx->ws_mesh);
     auto blk = [&](size_t off_per_cloud) { return base + off_per_cloud * chunk; };
     g.val = reinterpret_cast<float*>(blk(o_val));
@@ -952,7 +972,8 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
     double* area = reinterpret_cast<double*>(blk(o_area));
     g.count = reinterpret_cast<int*>(base + per * chunk);
     int* ntri = reinterpret_cast<int*>(base + per * chunk + al((size_t)chunk * 4));
-    std::vector<int> counts(chunk);
+    g.prev = reinterpret_cast<int*>(base + per * chunk + al((size_t)chunk * 4) * 2);
+    g.plan = reinterpret_cast<int*>(base + per * chunk + al((size_t)chunk * 4) * 3);
     ctx->mesh_points = 0;
     ctx->mesh_rounds = 0;
     for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -961,19 +982,38 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
         e = onet_fold(ctx, c + (size_t)b0 * ONET_C, nb, s, &ab);
         if (e == hipSuccess) e = launch_mise_init(g, nb, s);
         if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample init", e);
-        int max_count = (res0 + 1) * (res0 + 1) * (res0 + 1);
-        ctx->mesh_points += (unsigned long long)max_count * nb;
-        for (int round = 0; round < 64 && max_count > 0; ++round) {
-            ++ctx->mesh_rounds;
-            e = launch_onet_grid_eval(ctx->d_onet_img, ctx->d_onet_small, ab, g, nb, max_count, box, s);
+        // The MISE loop is driven from the device: queue lengths, the split of a round's decoder passes over the CUs and the
+        // clouds that are finished are all decided there (onet.hip grid_plan_kernel / onet_grid_eval_kernel, mesh.hip
+        // mise_begin_kernel).  The host only has to learn WHEN every queue has run empty, and it does so one round late: round r
+        // is enqueued before the queue lengths round r - 1 produced have been looked at (pinned copy + event per round, two
+        // slots), so the GPU never waits for the host; the one round enqueued past the end finds empty queues and is a handful of
+        // empty launches.
+        const int n0 = (res0 + 1) * (res0 + 1) * (res0 + 1);
+        ctx->mesh_points += (unsigned long long)n0 * nb;
+        bool done = false;
+        int round = 0;
+        for (; round < 64 && !done; ++round) {
+            int* slot = ctx->h_mesh_counts + (size_t)(round & 1) * ctx->h_mesh_counts_n;
+            e = launch_onet_grid_eval(ctx->d_onet_img, ctx->d_onet_small, ab, g, nb, ctx->n_cu, box, s);
             if (e == hipSuccess) e = launch_mise_update(g, nb, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), g.count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) e = hipMemcpyAsync(slot, g.count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipEventRecord(ctx->mesh_ev[round & 1], s);
+            if (e == hipSuccess && round >= 1) {
+                e = hipEventSynchronize(ctx->mesh_ev[(round - 1) & 1]);
+                const int* c_prev = ctx->h_mesh_counts + (size_t)((round - 1) & 1) * ctx->h_mesh_counts_n;   // queued BY round - 1 = evaluated IN this round
+                int max_count = 0;
+                for (int b = 0; b < nb; ++b) { max_count = c_prev[b] > max_count ? c_prev[b] : max_count; ctx->mesh_points += c_prev[b]; }
+                if (max_count > g.cap) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample: point queue overflow");
+                if (max_count == 0) done = true;           // this round (already enqueued) had nothing to do: the grid is complete
+                else ++ctx->mesh_rounds;
+            } else if (e == hipSuccess) {
+                ++ctx->mesh_rounds;                        // round 0 always has the coarse lattice to evaluate
+            }
             if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample round", e);
-            max_count = 0;
-            for (int b = 0; b < nb; ++b) { max_count = counts[b] > max_count ? counts[b] : max_count; ctx->mesh_points += counts[b]; }
-            if (max_count > g.cap) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample: point queue overflow");
         }
+        // the last enqueued round's copy must have landed before its slot is reused by the next chunk
+        e = hipEventSynchronize(ctx->mesh_ev[(round - 1) & 1]);
+        if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_onet_mesh_sample round", e);
         e = launch_mise_fill(g, nb, s);
         if (e == hipSuccess && grid)
             e = hipMemcpyAsync(grid + (size_t)b0 * g.P3, g.val, (size_t)nb * g.P3 * sizeof(float), hipMemcpyDeviceToDevice, s);

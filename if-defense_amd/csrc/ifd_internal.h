@@ -137,13 +137,15 @@ struct MiseGrid {
     uint8_t* sub;        // [B][sub_total]    voxel of level l subdivided (levels concatenated)
     uint8_t* mix;        // [B][sub_total]    scratch of one update round
     int* list;           // [B][cap]  grid-point indices to evaluate this round
-    int* count;          // [B]
+    int* count;          // [B]      queue length of this round (filled by the previous round's mise_apply_kernel)
+    int* prev;           // [B]      points evaluated in the round mise_update is closing (0: nothing new is known, the cloud is skipped)
+    int* plan;           // [B + 1]  exclusive prefix of the clouds' 128-point decoder passes of this round (grid_plan_kernel)
 };
 hipError_t launch_mise_init(const MiseGrid& g, int B, hipStream_t s);
 hipError_t launch_mise_update(const MiseGrid& g, int B, hipStream_t s);
 hipError_t launch_mise_fill(const MiseGrid& g, int B, hipStream_t s);
 hipError_t launch_onet_grid_eval(const float* img, const float* small, const float* ab, const MiseGrid& g, int B,
-                                 int max_count, float box, hipStream_t s);
+                                 int n_blocks, float box, hipStream_t s);
 hipError_t mc_upload_table();
 void mc_host_table(int8_t (*tri)[16], uint8_t* ntri);
 hipError_t launch_marching_cubes(const float* val, int B, int P, double iso, float box, int* cube_offs, int* ntri_total,

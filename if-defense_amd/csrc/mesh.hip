@@ -37,9 +37,21 @@ __global__ void mise_init_kernel(MiseGrid g) {
     if (i == 0) g.count[cloud] = n0 * n0 * n0;
 }
 
+// Opens an update round: prev = the number of points the round has just evaluated, count = 0 (the queue mise_apply_kernel
+// refills).  A cloud with prev == 0 has learnt nothing since its last update: its marks would be the ones already applied, so
+// the mark / apply blocks of that cloud return at once - clouds that finish early stop costing anything, and a whole round
+// without work (the host enqueues one round ahead of the counts it has seen, api.cpp) is a handful of empty launches.
+__global__ void mise_begin_kernel(MiseGrid g, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    g.prev[b] = min(g.count[b], g.cap);
+    g.count[b] = 0;
+}
+
 // mixed[level][voxel] = leaf && known points of the closed cube on both sides of the threshold
 __global__ void mise_mark_kernel(MiseGrid g, int level) {
     const int cloud = blockIdx.y;
+    if (g.prev[cloud] == 0) return;                                 // block-uniform
     const int nv = g.res0 << level;                                 // voxels per axis at this level
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nv * nv * nv) return;
@@ -75,6 +87,7 @@ __global__ void mise_mark_kernel(MiseGrid g, int level) {
 // single-slot atomics on one counter per cloud serialise (measured: 16 % of the whole mesh path).
 __global__ void mise_apply_kernel(MiseGrid g, int level) {
     const int cloud = blockIdx.y;
+    if (g.prev[cloud] == 0) return;                                 // block-uniform (before the wave-level prefix sum)
     const int nv = g.res0 << level;
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = v < nv * nv * nv && g.mix[(size_t)cloud * g.sub_total + g.sub_off[level] + v] != 0;
@@ -175,8 +188,7 @@ hipError_t launch_mise_init(const MiseGrid& g, int B, hipStream_t s) {
 hipError_t launch_mise_update(const MiseGrid& g, int B, hipStream_t s) {
     // the evaluated points are known now; decisions of this round use the state at its start (mise.pyx:196-215:
     // marks first, then subdivision of the voxels that existed), so: reset the queue, mark every level, then apply
-    hipError_t e = hipMemsetAsync(g.count, 0, (size_t)B * sizeof(int), s);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mise_begin_kernel, dim3((B + 255) / 256), dim3(256), 0, s, g, B);
     for (int l = 0; l < g.depth; ++l) {
         const int nv = g.res0 << l, n = nv * nv * nv;
         hipLaunchKernelGGL(mise_mark_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, g, l);
@@ -295,42 +307,108 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(int* __restrict__ ntri, i
     if (threadIdx.x == 0) total[blockIdx.x] = carry;
 }
 
-// pass 2: emit the triangles (vertex coordinates in the decoder's frame, generation.py:171-176) and their areas
+// The same exclusive scan in three phases over chunks of 2048 cubes (round 5: the one-block-per-cloud scan above walked 2.2 M
+// counts in 268 steps of 22 barriers each, 64 workgroups on 256 CUs - 3.3 ms per 64 clouds; integer sums: the same offsets).
+constexpr int SCAN_CHUNK = 2048;
+__global__ __launch_bounds__(256) void mc_chunk_sum_kernel(const int* __restrict__ ntri, int n, int* __restrict__ sums, size_t sums_stride) {
+    __shared__ int wsum[4];
+    const int* a = ntri + (size_t)blockIdx.y * n;
+    const int i0 = blockIdx.x * SCAN_CHUNK + threadIdx.x * 8;
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += i0 + j < n ? a[i0 + j] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[(size_t)blockIdx.y * sums_stride + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(1024) void mc_chunk_scan_kernel(int* __restrict__ sums, size_t sums_stride, int nchunks, int* __restrict__ total) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    int* a = sums + (size_t)blockIdx.x * sums_stride;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nchunks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nchunks ? a[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nchunks) a[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[blockIdx.x] = carry;
+}
+__global__ __launch_bounds__(256) void mc_chunk_apply_kernel(int* __restrict__ ntri, int n, const int* __restrict__ sums, size_t sums_stride) {
+    __shared__ int wsum[4];
+    int* a = ntri + (size_t)blockIdx.y * n;
+    const int i0 = blockIdx.x * SCAN_CHUNK + threadIdx.x * 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int v[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = i0 + j < n ? a[i0 + j] : 0; sum += v[j]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = sums[(size_t)blockIdx.y * sums_stride + blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (i0 + j < n) a[i0 + j] = run; run += v[j]; }
+}
+
+// pass 2: emit the triangles (vertex coordinates in the decoder's frame, generation.py:171-176) and their areas.  One thread per
+// TRIANGLE (round 5; one thread per cube left 95 % of every wave idle behind the two or three lanes whose cube is cut by the
+// surface): triangle `at` of a cloud belongs to the last cube whose offset is <= at (cubes without triangles share their
+// successor's offset and are stepped over by the search), t = at - offset of that cube.  Same arithmetic, same order.
 __global__ void mc_emit_kernel(const float* __restrict__ val, int P, double iso, float box, const int* __restrict__ offs,
-                               int cap, float* __restrict__ tris, double* __restrict__ area) {
-    const int cloud = blockIdx.y, NC = P + 1;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= NC * NC * NC) return;
+                               const int* __restrict__ ntri_total, int cap, float* __restrict__ tris, double* __restrict__ area) {
+    const int cloud = blockIdx.y, NC = P + 1, ncube = NC * NC * NC;
+    const int at = blockIdx.x * blockDim.x + threadIdx.x;
+    if (at >= min(ntri_total[cloud], cap)) return;
+    const int* of = offs + (size_t)cloud * ncube;
+    int lo = 0, hi = ncube - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (of[mid] <= at) lo = mid; else hi = mid - 1;
+    }
+    const int c = lo, t = at - of[c];
     const int x = c / (NC * NC), y = (c / NC) % NC, z = c % NC;
     double f[8];
     const int cfg = cube_config(val + (size_t)cloud * P * P * P, P, x, y, z, iso, f);
-    const int n = c_mc.ntri[cfg];
-    if (n == 0) return;
     const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
     const int ec[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
-    int at = offs[(size_t)cloud * NC * NC * NC + c];
-    for (int t = 0; t < n && at < cap; ++t, ++at) {
-        double p[3][3];
+    double p[3][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int e = c_mc.tri[cfg][3 * t + k], a = ec[e][0], b = ec[e][1];
-            // mc_isovalue_interpolation (marchingcubes.cpp:290-297)
-            const double w = f[b] == f[a] ? 0.5 : (iso - f[a]) / (f[b] - f[a]);
-            const double gx = x + ox[a] + (ox[b] - ox[a]) * w, gy = y + oy[a] + (oy[b] - oy[a]) * w,
-                         gz = z + oz[a] + (oz[b] - oz[a]) * w;
-            // libmcubes' +0.5 shift undone, padding undone, normalised to the bounding box (generation.py:171-176)
-            p[k][0] = (double)box * ((gx - 1.0) / (double)(P - 1) - 0.5);
-            p[k][1] = (double)box * ((gy - 1.0) / (double)(P - 1) - 0.5);
-            p[k][2] = (double)box * ((gz - 1.0) / (double)(P - 1) - 0.5);
-        }
-        float* o = tris + ((size_t)cloud * cap + at) * 9;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { o[3 * k] = (float)p[k][0]; o[3 * k + 1] = (float)p[k][1]; o[3 * k + 2] = (float)p[k][2]; }
-        const double ux = p[1][0] - p[0][0], uy = p[1][1] - p[0][1], uz = p[1][2] - p[0][2];
-        const double vx = p[2][0] - p[0][0], vy = p[2][1] - p[0][1], vz = p[2][2] - p[0][2];
-        const double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
-        area[(size_t)cloud * cap + at] = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
+    for (int k = 0; k < 3; ++k) {
+        const int e = c_mc.tri[cfg][3 * t + k], a = ec[e][0], b = ec[e][1];
+        // mc_isovalue_interpolation (marchingcubes.cpp:290-297)
+        const double w = f[b] == f[a] ? 0.5 : (iso - f[a]) / (f[b] - f[a]);
+        const double gx = x + ox[a] + (ox[b] - ox[a]) * w, gy = y + oy[a] + (oy[b] - oy[a]) * w,
+                     gz = z + oz[a] + (oz[b] - oz[a]) * w;
+        // libmcubes' +0.5 shift undone, padding undone, normalised to the bounding box (generation.py:171-176)
+        p[k][0] = (double)box * ((gx - 1.0) / (double)(P - 1) - 0.5);
+        p[k][1] = (double)box * ((gy - 1.0) / (double)(P - 1) - 0.5);
+        p[k][2] = (double)box * ((gz - 1.0) / (double)(P - 1) - 0.5);
     }
+    float* o = tris + ((size_t)cloud * cap + at) * 9;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[3 * k] = (float)p[k][0]; o[3 * k + 1] = (float)p[k][1]; o[3 * k + 2] = (float)p[k][2]; }
+    const double ux = p[1][0] - p[0][0], uy = p[1][1] - p[0][1], uz = p[1][2] - p[0][2];
+    const double vx = p[2][0] - p[0][0], vy = p[2][1] - p[0][1], vz = p[2][2] - p[0][2];
+    const double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+    area[(size_t)cloud * cap + at] = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
 }
 
 // inclusive scan of the triangle areas (double), one block per cloud
@@ -405,8 +483,18 @@ hipError_t launch_marching_cubes(const float* val, int B, int P, double iso, flo
                                  int cap, float* tris, double* area, hipStream_t s) {
     const int NC = P + 1, n = NC * NC * NC;
     hipLaunchKernelGGL(mc_count_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, val, P, iso, cube_offs);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(B), dim3(1024), 0, s, cube_offs, n, ntri_total);
-    hipLaunchKernelGGL(mc_emit_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, val, P, iso, box, cube_offs, cap, tris, area);
+    // chunk sums live in the area buffer, which nobody reads before mc_emit_kernel writes it (double[cap] per cloud = 2 cap ints)
+    const int nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if ((size_t)nchunks <= (size_t)cap * 2) {
+        int* sums = reinterpret_cast<int*>(area);
+        const size_t stride = (size_t)cap * 2;
+        hipLaunchKernelGGL(mc_chunk_sum_kernel, dim3(nchunks, B), dim3(256), 0, s, cube_offs, n, sums, stride);
+        hipLaunchKernelGGL(mc_chunk_scan_kernel, dim3(B), dim3(1024), 0, s, sums, stride, nchunks, ntri_total);
+        hipLaunchKernelGGL(mc_chunk_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, cube_offs, n, sums, stride);
+    } else {
+        hipLaunchKernelGGL(mc_scan_kernel, dim3(B), dim3(1024), 0, s, cube_offs, n, ntri_total);
+    }
+    hipLaunchKernelGGL(mc_emit_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, val, P, iso, box, cube_offs, ntri_total, cap, tris, area);
     hipLaunchKernelGGL(area_scan_kernel, dim3(B), dim3(1024), 0, s, area, ntri_total, cap);
     return hipGetLastError();
 }

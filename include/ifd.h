@@ -16,8 +16,8 @@
  *     name ends in _host.  float = IEEE binary32.  Arrays are dense, row-major.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
  *     only enqueue work on it and return; the host blocks in: ifd_create /
- *     ifd_onet_create / ifd_destroy, ifd_get_counters, ifd_onet_mesh_sample (one
- *     stream synchronisation per MISE round), and in a call that needs more
+ *     ifd_onet_create / ifd_destroy, ifd_get_counters, ifd_onet_mesh_sample (waits
+ *     on one event per MISE round, a round behind what it has enqueued), and in a call that needs more
  *     context workspace than any earlier call on that context (a one-time
  *     device synchronisation while the workspace grows).
  *   - a context is bound to the device given to ifd_create: every entry point
@@ -306,7 +306,9 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
  * to_dense()), triangles [B,max_triangles,9] float32 (three xyz vertices per triangle in the decoder's frame; the
  * first n_triangles[b] rows are valid).  The surface samples use the counter-based generator of ifd_prepare, keyed by
  * (seed, cloud_index_base + b, sample index) - the reference's are unseeded numpy draws.
- * Synchronises the stream once per MISE round (the host reads the number of queued grid points). */
+ * The MISE loop is driven from the device (queue lengths, the split of a round's decoder passes over the CUs, finished clouds);
+ * the host enqueues round r before it has looked at what round r - 1 queued and waits on one event per round only to learn when
+ * every queue has run empty - the GPU never waits for the host. */
 typedef struct ifd_mesh_params {
     int32_t struct_size;       /* sizeof(ifd_mesh_params) */
     int32_t resolution0;       /* cfg generation.resolution_0 (32) */
