@@ -388,6 +388,27 @@ def extras(dev):
         r.close()
     except Exception as e:      # noqa: BLE001
         out["trained_like"] = {"error": str(e)[:200]}
+    try:      # clouds of more than 1024 optimised points (--sample_npoint 2048): the two-launch-per-step path against the persistent kernel
+        w = I.weights.pack_state_dict(I.weights.random_state_dict(0))
+        r = I.Restorer(w, device=dev)
+        x = torch.from_numpy(synth_clouds(256)).to(dev)
+        per = {}
+        for k_opt, steps in ((1024, 51), (2048, 11)):
+            prep = r.prepare(x, r.sor(x), n_sel=600, n_opt=k_opt, seed=1234)
+            planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+            r.optimize_points(prep["init"][:8], planes[:8], rep_weight=500.0, steps=2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps)
+            torch.cuda.synchronize()
+            per[k_opt] = (time.perf_counter() - t0) / (256.0 * k_opt * steps)
+        out["k2048"] = {"value": round(1.0 / (per[2048] * 2048 * (ITERATIONS + 1)), 2), "unit": "clouds/s (2048 optimised points each, optimiser only)",
+                        "per_point_cost_vs_1024": round(per[2048] / per[1024], 2),
+                        "what": "ifd_optimize on 256 clouds x 2048 points (two launches per Adam step, exact brute-force 5-NN: DESIGN section 4.6), "
+                                "11 of 501 steps scaled; per_point_cost_vs_1024 = time per point and step over the persistent kernel's on 256 clouds x 1024"}
+        r.close()
+    except Exception as e:      # noqa: BLE001
+        out["k2048"] = {"error": str(e)[:200]}
     try:      # ONet-Opt decoder variant: 256 clouds x 51 steps, scaled to 501
         r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device=dev)
         x = torch.from_numpy(synth_clouds(256)).to(dev)

@@ -878,6 +878,8 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
+    if (prm->precision != 0)
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: ifd_opt_params.precision must be 0 - the split-precision tiles exist for the ConvONet decoder only");
     OptArgs a{};
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
     a.knn_scan_every_step = prm->knn_reference_form ? 2 : (prm->knn_scan_every_step ? 1 : 0);

@@ -34,6 +34,7 @@ class DefenseArgs:
     chunk: int = 4096               # extension: clouds per device pass (memory knob, ~17 MB of scratch per cloud;
                                     # does not change results)
     printing: bool = False          # optimize_points(..., printing=True) of the reference (opt_defense.py:229-236)
+    precision: str = "f32"          # extension (opt-in): "bf16x6" (f32-equivalent) / "bf16x3" (reduced) decoder layers, ifd_opt_params.precision
 
 
 def _prepare_unit(r: Restorer, xb: torch.Tensor, args: DefenseArgs, base: int, total: int):
@@ -134,7 +135,8 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
                 main.wait_event(ev)
             h["out"][lo:hi] = r.optimize_points(init, planes, rep_weight=args.rep_weight, iterations=args.iterations,
                                                 lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing,
-                                                **({"check": False} if on_gpu and hasattr(r, "check_status") else {}))
+                                                **({"check": False} if on_gpu and hasattr(r, "check_status") else {}),
+                                                **({"precision": args.precision} if getattr(args, "precision", "f32") != "f32" else {}))
         ready = launch_prepare(nxt_u) if nxt_u is not None else None               # rides on the optimiser's tail
         if last:
             if on_gpu and hasattr(r, "check_status") and os.environ.get("IFD_STATUS_CHECK", "1") != "0":

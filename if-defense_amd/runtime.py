@@ -233,7 +233,7 @@ class Restorer:
         """
         if printing and state is None and not return_state and not return_loss:
             return self._optimize_points_printing(opt_points, c, rep_weight, int(iterations) + 1 if steps is None else int(steps),
-                                                  lr, loss_batch, normalize, knn_scan_every_step)
+                                                  lr, loss_batch, normalize, knn_scan_every_step, precision)
         planes = self._cond(c)
         p = _f32(opt_points, self.device).clone()
         B, K = p.shape[:2]
@@ -268,7 +268,7 @@ class Restorer:
             out += (loss,)
         return out if len(out) > 1 else p
 
-    def _optimize_points_printing(self, opt_points, c, rep_weight, n_steps, lr, loss_batch, normalize, scan):
+    def _optimize_points_printing(self, opt_points, c, rep_weight, n_steps, lr, loss_batch, normalize, scan, precision=None):
         """printing=True of the reference's optimize_points (opt_defense.py:229-236): at iterations 0, 100, 200, ... it
         prints the loss, the two loss terms and the mean occupancy probability, all evaluated at that iteration's
         pre-update points.  The run is cut so that every such iteration is a launch of its own (the kernel reports the
@@ -286,14 +286,14 @@ class Restorer:
                 last = nxt == n_steps
                 p, st = self.optimize_points(p, c, rep_weight=rep_weight, steps=nxt - t, lr=lr, loss_batch=loss_batch,
                                              normalize=normalize and last, state=st, return_state=True,
-                                             knn_scan_every_step=scan)
+                                             knn_scan_every_step=scan, precision=precision)
                 t = nxt
                 continue
             prob = float(torch.sigmoid(self.decode(p, c)).mean())               # occ_value of iteration t (pre-update points)
             last = t + 1 == n_steps
             p, st, loss = self.optimize_points(p, c, rep_weight=rep_weight, steps=1, lr=lr, loss_batch=loss_batch,
                                                normalize=normalize and last, state=st, return_state=True, return_loss=True,
-                                               knn_scan_every_step=scan)
+                                               knn_scan_every_step=scan, precision=precision)
             l = loss.double().cpu()
             if torch.is_tensor(loss_batch):
                 lbv = loss_batch.double().cpu()

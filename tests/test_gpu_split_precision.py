@@ -185,3 +185,40 @@ def test_split_precision_trained_like_field():
             assert np.median(d) < 1e-4 and (d > 1e-3).mean() <= (d32 > 1e-3).mean() + 0.004, mode
     finally:
         r.close()
+
+
+def test_cli_precision_flag_and_onet_rejection(tmp_path, np_weights):
+    """`--precision` of the ConvONet CLI (an opt-in extension; the reference has no such flag): the whole pipeline with the split-precision
+    tiles writes the same file layout, bf16x6 lands on the f32 run's points after 20 iterations (the two are f32-equivalent, short horizon),
+    and the ONet entry point refuses the parameter instead of silently running f32."""
+    import os, subprocess, sys
+    import ifdefense_amd as I
+    wpath = tmp_path / "convonet.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in np_weights.items()}, wpath)
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "convonet_golden.npz")))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in MODES:
+        d = tmp_path / mode
+        d.mkdir()
+        np.savez(d / "adv.npz", test_pc=g["raw"], test_label=np.array([0, 8, 30, 39]))
+        r = subprocess.run([sys.executable, "-m", "ifdefense_amd.opt_defense", "--data_root", str(d / "adv.npz"), "--iterations=20",
+                            "--weights", str(wpath), "--seed=5", "--precision", mode], capture_output=True, text=True, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[mode] = np.load(d / "ConvONet-Opt" / "convonet_opt-adv.npz")["test_pc"]
+        assert outs[mode].shape == (4, 1024, 3) and np.isfinite(outs[mode]).all()
+    d6 = np.linalg.norm(outs["bf16x6"] - outs["f32"], axis=-1)
+    d3 = np.linalg.norm(outs["bf16x3"] - outs["f32"], axis=-1)
+    print("CLI, 21 steps + normalisation against the f32 run: bf16x6 max %.2e (points > 1e-3: %d), bf16x3 max %.2e (points > 1e-3: %d)" %
+          (d6.max(), int((d6 > 1e-3).sum()), d3.max(), int((d3 > 1e-3).sum())))
+    assert not np.array_equal(outs["bf16x6"], outs["f32"])                  # the flag reached the kernel
+    assert np.median(d6) < 1e-6 and (d6 > 1e-3).sum() <= 4 and np.median(d3) < 1e-5 and (d3 > 1e-3).sum() <= 16
+    ro = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device="cuda:0")
+    try:
+        c = torch.zeros(2, 512)
+        p = (torch.rand(2, 64, 3) - 0.5) * 0.5
+        with pytest.raises(I.IfdError, match="ConvONet decoder only"):
+            ro.optimize_points(p, c, iterations=2, precision="bf16x6")
+        assert ro.optimize_points(p, c, iterations=2).shape == (2, 64, 3)
+    finally:
+        ro.close()
