@@ -424,6 +424,18 @@ def extras(dev):
         out["onet_opt"] = {"value": round(256 / (dt * (ITERATIONS + 1) / 51), 2), "unit": "clouds/s",
                            "roofline_frac": round(flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                            "what": "ifd_onet_optimize, 256 clouds x 51 of 501 Adam steps, scaled (optimiser only)"}
+        sp = {}
+        for mode in ("bf16x6", "bf16x3"):     # the opt-in split-precision passes of the same launch (onet_kernel.h onet_pass_bf)
+            r.optimize_points(prep["init"][:8], c[:8], rep_weight=500.0, steps=2, precision=mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.optimize_points(prep["init"], c, rep_weight=500.0, steps=51, precision=mode)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            sp[mode] = {"value": round(256 / (dts * (ITERATIONS + 1) / 51), 2), "unit": "clouds/s",
+                        "f32_equivalent_tflops": round(flop / dts / 1e12, 1),
+                        "precision": "f32-equivalent" if mode == "bf16x6" else "REDUCED (2^-17 relative per product)"}
+        out["onet_opt"]["split_precision"] = sp
         # ONet-Mesh: MISE grid + marching cubes + surface samples, threshold at the field's median
         gq = torch.Generator().manual_seed(9)
         med = float(r.decode((torch.rand(8, 4096, 3, generator=gq) - 0.5) * 1.1, c[:8]).median())

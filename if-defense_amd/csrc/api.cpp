@@ -110,6 +110,7 @@ struct ifd_ctx {
     // (10 forward + 10 transposed), the small decoder parameters, tensor offsets into d_w
     int model = IFD_MODEL_CONVONET;
     float* d_onet_img = nullptr;
+    float* d_onet_img_bf = nullptr; // ... the same layers as bf16 pieces (split precision, onet_fragment_image_bf)
     float* d_onet_small = nullptr;
     OnetEncOffsets oe{};
     OnetDecOffsets od{};
@@ -421,6 +422,33 @@ void onet_fragment_image(const float* W, bool transposed, float* img) {
                 }
 }
 
+// The same layer as bf16 PIECES for the 16x16x32 bf16 MFMA A operand (onet_kernel.h, split precision): w = w1 + w2 + w3 exactly
+// (bf16_rne of what the earlier pieces left).  Chunks of 24 KB = [8 output tiles t8][3 pieces][64 lanes][8 k-slots]: lane (m = l & 15,
+// g = l >> 4), slot j of k-step s multiplies input value 8 s + j of the lane that holds it = channel 32 s + 16 (j >> 2) + 4 g + (j & 3);
+// output tile t = 8 h + t8, row m.  Chunk order: k-step-major (2 s + h), or output-half-major (8 h + s) for the images the backward
+// chain sweeps twice (W0^T).
+void onet_fragment_image_bf(const float* W, bool transposed, bool half_major, uint16_t* img) {
+    for (int s = 0; s < 8; ++s)
+        for (int h = 0; h < 2; ++h) {
+            uint16_t* chunk = img + (size_t)(half_major ? 8 * h + s : 2 * s + h) * (8 * 3 * 64 * 8);
+            for (int t8 = 0; t8 < 8; ++t8)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = 16 * (8 * h + t8) + (lane & 15), g = lane >> 4;
+                        const int k = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+                        float rest = transposed ? W[(size_t)k * ONET_H + m] : W[(size_t)m * ONET_H + k];
+                        for (int pc = 0; pc < 3; ++pc) {
+                            const uint16_t b = bf16_rne(rest);
+                            chunk[((size_t)(t8 * 3 + pc) * 64 + lane) * 8 + j] = b;
+                            uint32_t bits = (uint32_t)b << 16;
+                            float piece;
+                            std::memcpy(&piece, &bits, 4);
+                            rest -= piece;                       // exact: the piece shares the leading bits of what it was rounded from
+                        }
+                    }
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -542,6 +570,7 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
     if (ctx->ws_enc) (void)hipFree(ctx->ws_enc);
     if (ctx->d_onet_img) (void)hipFree(ctx->d_onet_img);
+    if (ctx->d_onet_img_bf) (void)hipFree(ctx->d_onet_img_bf);
     if (ctx->d_onet_small) (void)hipFree(ctx->d_onet_small);
     if (ctx->ws_mesh) (void)hipFree(ctx->ws_mesh);
     if (ctx->h_mesh_counts) (void)hipHostFree(ctx->h_mesh_counts);
@@ -789,6 +818,18 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
         onet_fragment_image(w + m.fc1_w[i].host_off, true, img.data() + (size_t)(10 + 2 * (4 - i)) * L);
         onet_fragment_image(w + m.fc0_w[i].host_off, true, img.data() + (size_t)(11 + 2 * (4 - i)) * L);
     }
+    // the bf16 piece images of the same twenty layers (W0^T output-half-major), packed into a float vector for the upload helper
+    const size_t LB = (size_t)16 * (8 * 3 * 64 * 8);              // uint16 per layer image
+    std::vector<float> img_bf(20 * LB / 2);
+    {
+        uint16_t* ib = reinterpret_cast<uint16_t*>(img_bf.data());
+        for (int i = 0; i < 5; ++i) {
+            onet_fragment_image_bf(w + m.fc0_w[i].host_off, false, false, ib + (size_t)(2 * i) * LB);
+            onet_fragment_image_bf(w + m.fc1_w[i].host_off, false, false, ib + (size_t)(2 * i + 1) * LB);
+            onet_fragment_image_bf(w + m.fc1_w[i].host_off, true, false, ib + (size_t)(10 + 2 * (4 - i)) * LB);
+            onet_fragment_image_bf(w + m.fc0_w[i].host_off, true, true, ib + (size_t)(11 + 2 * (4 - i)) * LB);
+        }
+    }
     // small parameters, in the LDS order of onet.hip: fc_p [256][4] | fc_1 biases [5][256] | fc_out w [256] | b
     std::vector<float> small((size_t)onet_small_floats(), 0.f);
     for (int c = 0; c < ONET_H; ++c) {
@@ -807,6 +848,7 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     };
     upload(&ctx->d_w, dev);
     upload(&ctx->d_onet_img, img);
+    upload(&ctx->d_onet_img_bf, img_bf);
     upload(&ctx->d_onet_small, small);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
@@ -815,6 +857,7 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e == hipSuccess) e = configure_onet_kernels();
+    if (e == hipSuccess) e = configure_onet_bf_kernels();
     if (e == hipSuccess) e = mc_upload_table();
     if (e != hipSuccess) {
         g_create_error = std::string("ifd_onet_create: ") + hipGetErrorString(e);
@@ -878,8 +921,8 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if ((m == nullptr) != (v == nullptr)) return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: pass both m and v or neither");
     if (prm->steps < 0 || prm->t0 < 0 || prm->loss_batch < 1 || (prm->t0 > 0 && !m))
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: bad steps/t0/loss_batch (t0 > 0 needs m and v)");
-    if (prm->precision != 0)
-        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: ifd_opt_params.precision must be 0 - the split-precision tiles exist for the ConvONet decoder only");
+    if (prm->precision < 0 || prm->precision > 2)
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_optimize: precision must be 0 (f32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
     OptArgs a{};
     a.steps = prm->steps; a.t0 = prm->t0; a.loss_batch = prm->loss_batch; a.normalize = prm->normalize;
     a.knn_scan_every_step = prm->knn_reference_form ? 2 : (prm->knn_scan_every_step ? 1 : 0);
@@ -900,6 +943,10 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (e == hipSuccess && large)
         e = launch_onet_large_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
                                        ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K, a, s);
+    else if (e == hipSuccess && prm->precision != 0)      // (clouds beyond 1024 points: the launch-per-step path has the f32 pass only)
+        e = launch_onet_optimize_bf(prm->precision, ctx->d_onet_img_bf, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
+                                    static_cast<uint16_t*>(ctx->ws), ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K,
+                                    a, s);
     else if (e == hipSuccess)
         e = launch_onet_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
                                  static_cast<uint16_t*>(ctx->ws), ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K,

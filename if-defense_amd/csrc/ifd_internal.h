@@ -106,6 +106,11 @@ struct OnetDecOffsets {
     int cbn_gamma_w[11], cbn_gamma_b[11], cbn_beta_w[11], cbn_beta_b[11], cbn_mean[11], cbn_var[11], fc0_b[5];
 };
 hipError_t configure_onet_kernels();
+hipError_t configure_onet_bf_kernels();
+// split-precision ONet-Opt launch (onet_bf.hip): img_bf = the bf16 piece image of api.cpp onet_fragment_image_bf, precision 1 | 2
+hipError_t launch_onet_optimize_bf(int precision, const float* img_bf, const float* small, const float* ab, float* p, float* m, float* v,
+                                   float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters,
+                                   const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s);
 size_t onet_encode_ws_floats(int B, int Tmax);
 int onet_small_floats();
 hipError_t launch_onet_encode(const float* w, const OnetEncOffsets& eo, const float* sel, const int* t_per_cloud, int B,

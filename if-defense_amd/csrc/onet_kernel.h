@@ -1,0 +1,616 @@
+// Device code of the ONet decoder pass and of the persistent ONet-Opt optimiser kernel, shared by onet.hip (f32: PREC 0) and
+// onet_bf.hip (split precision: PREC 1 / 2, built without packed-f32 instructions - see split_bf16.h).  Included inside namespace ifd.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// decoder pass: 128 points (16 per wave) forward + input-backward through the ten 256x256 layers
+// ---------------------------------------------------------------------------------------------
+constexpr int CHUNK_FLOATS = 2 * 64 * 64;            // 2 output tiles x 64 k-steps x 64 lanes = 32 KB
+constexpr int CHUNKS_PER_LAYER = 8;
+constexpr int N_IMG = 20;                            // fwd fc_0/fc_1 of 5 blocks, then their transposes in backward order
+constexpr int N_CHUNKS = N_IMG * CHUNKS_PER_LAYER;   // 160 per pass
+// LDS layout (floats)
+constexpr int OL_CHUNK = 0;                                          // [2][CHUNK_FLOATS]
+constexpr int OL_AB = OL_CHUNK + 2 * CHUNK_FLOATS;                   // [11][2][256]  CBN a, b of this cloud
+constexpr int OL_FCP = OL_AB + ONET_NCBN * 2 * ONET_H;               // [256][4]      fc_p {w0, w1, w2, bias}
+constexpr int OL_B1 = OL_FCP + ONET_H * 4;                           // [5][256]      fc_1 biases
+constexpr int OL_WOUT = OL_B1 + 5 * ONET_H;                          // [256] + bout (+3 pad)
+constexpr int OL_END = OL_WOUT + ONET_H + 4;
+constexpr int ONET_SMALL_FLOATS = OL_END - OL_FCP;                   // what the host packs behind the CBN block
+
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ img, float* __restrict__ lds, int g, int wave, int lane) {
+    // chunk g of the circular weight stream -> buffer g & 1; 32 pieces of 1 KiB, 4 per wave
+    const float* src = img + (size_t)g * CHUNK_FLOATS + wave * 1024 + lane * 4;
+    float* dst = lds + OL_CHUNK + (g & 1) * CHUNK_FLOATS + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+}
+
+// One 256x256 layer on the wave's 16 points: out[t] (+)= sum_s A_frag(t, s) * in[s].  g = index of the layer's first
+// chunk in the weight stream; chunk g is resident in LDS on entry, chunk g + 8 on exit.
+__device__ __forceinline__ void layer_mfma(const float* __restrict__ img, float* __restrict__ lds, int g, int wave, int lane,
+                                           const float (&in)[64], f32x4 (&out)[16]) {
+#pragma unroll
+    for (int c = 0; c < CHUNKS_PER_LAYER; ++c) {
+        int gn = g + c + 1;
+        if (gn >= N_CHUNKS) gn -= N_CHUNKS;
+        stage_chunk(img, lds, gn, wave, lane);                       // prefetch the next chunk into the other buffer
+        const f32x4* a = reinterpret_cast<const f32x4*>(lds + OL_CHUNK + ((g + c) & 1) * CHUNK_FLOATS) + lane;
+        // A fragments one k-group ahead; the sched_barrier keeps the scheduler from hoisting all 32 fragment reads of
+        // the chunk to its top (128 VGPRs -> spills)
+        f32x4 a0 = a[0], a1 = a[16 * 64];
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+            f32x4 n0 = a0, n1 = a1;
+            if (s4 + 1 < 16) { n0 = a[(s4 + 1) * 64]; n1 = a[(16 + s4 + 1) * 64]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                out[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], in[4 * s4 + j], out[2 * c], 0, 0, 0);
+                out[2 * c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], in[4 * s4 + j], out[2 * c + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0; a1 = n1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // my pieces of the next chunk have landed
+        __builtin_amdgcn_s_barrier();                                // everybody's have, and everybody is done with this one
+    }
+}
+
+// ReLU masks of the 64 channels a lane holds: bit (31 - k % 32) of word k / 32 = "value k is NOT positive".  One
+// v_alignbit per value going in (the sign of bits(relu(v)) - 1), v_bfe_i32 + v_bfi per value coming out - every
+// vector instruction costs SIMD time next to the MFMAs.
+struct Mask64 {
+    unsigned int w[2];
+};
+// u = relu(a x + b) for the 64 channels this lane holds; returns the ReLU mask
+__device__ __forceinline__ Mask64 cbn_relu(const float* __restrict__ ab, int q, const f32x4 (&x)[16], float (&u)[64]) {
+    Mask64 m = {{0u, 0u}};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ab + 16 * t + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ab + ONET_H + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(a[r], x[t][r], b[r]);
+            const int ri = max(__float_as_int(v), 0);                  // ReLU on the bits (-0.0 and negatives -> +0)
+            u[4 * t + r] = __int_as_float(ri);
+            m.w[(4 * t + r) >> 5] = __builtin_amdgcn_alignbit(m.w[(4 * t + r) >> 5], (unsigned int)ri - 1u, 31);
+        }
+    }
+    asm("" : "+v"(m.w[0]), "+v"(m.w[1]));     // keep them bit-masks (not volatile: dropped with the masks in forward-only passes)
+    return m;
+}
+// val where value k passed its ReLU, else +0
+__device__ __forceinline__ float relu_gate(const Mask64& m, int k, float val) {
+    const int dead = (int)(m.w[k >> 5] << (k & 31)) >> 31;            // v_bfe_i32: 0 / -1
+    unsigned int o;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(o) : "v"(dead), "v"(__float_as_uint(val)));      // val & ~dead
+    return __uint_as_float(o);
+}
+
+constexpr int OMODE_SUM = 0;      // d(sum of logits)/dp, loss = logits          (ifd_onet_decode)
+constexpr int OMODE_OPT = 1;      // BCE-with-logits against `threshold`, scaled by inv_lb  (optimiser)
+
+// Forward + backward of one 16-point sub-tile per wave.  (x0, x1, x2) = the point of lane n (all four q-lanes of
+// a point pass the same coordinates).  All 8 waves of the block call this together (it contains barriers).
+template <int MODE, bool WANT_GRAD>
+__device__ __forceinline__ void onet_pass(const float* __restrict__ img, float* __restrict__ lds, int wave, int lane,
+                                          float x0, float x1, float x2, float threshold, float inv_lb, float& logit,
+                                          float& bce, float (&dx)[3]) {
+    const int q = lane >> 4;
+    const float* ab = lds + OL_AB;
+    f32x4 x[16], acc[16];
+    float u[64];
+    Mask64 m0[5], m1[5], mf;
+    // fc_p (decoder.py:118)
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_FCP + (16 * t + 4 * q + r) * 4);
+            x[t][r] = fmaf(w.z, x2, fmaf(w.y, x1, fmaf(w.x, x0, w.w)));
+        }
+    // five CResnetBlockConv1d (layers.py:97-107): x += fc_1(relu(bn_1(fc_0(relu(bn_0(x))))))
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        m0[i] = cbn_relu(ab + (2 * i) * 2 * ONET_H, q, x, u);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};          // fc_0 bias is folded into bn_1
+        layer_mfma(img, lds, (2 * i) * CHUNKS_PER_LAYER, wave, lane, u, acc);
+        m1[i] = cbn_relu(ab + (2 * i + 1) * 2 * ONET_H, q, acc, u);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] += *reinterpret_cast<const f32x4*>(lds + OL_B1 + i * ONET_H + 16 * t + 4 * q);
+        layer_mfma(img, lds, (2 * i + 1) * CHUNKS_PER_LAYER, wave, lane, u, x);
+    }
+    // fc_out(relu(bn(x)))  (decoder.py:130)
+    mf = cbn_relu(ab + 10 * 2 * ONET_H, q, x, u);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_WOUT + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(w[r], u[4 * t + r], part);
+    }
+    part = add_lane_xor32(add_lane_xor16(part));
+    logit = part + lds[OL_WOUT + ONET_H];
+    float dl;
+    if (MODE == OMODE_OPT) {
+        // F.binary_cross_entropy_with_logits (opt_defense.py:213): max(x,0) - x t + log1p(exp(-|x|))
+        const float e = expf(-fabsf(logit));
+        bce = fmaxf(logit, 0.f) - logit * threshold + log1pf(e);
+        const float sig = logit >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        dl = (sig - threshold) * inv_lb;
+    } else {
+        bce = logit;
+        dl = 1.f;
+    }
+    dx[0] = dx[1] = dx[2] = 0.f;
+    if (!WANT_GRAD) {
+        // the next pass starts at chunk 0 again: skip the ten backward images (chunk 80, staged by the last layer,
+        // is not read by anybody)
+        stage_chunk(img, lds, 0, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    // ---- backward (parameters frozen: only d/dx).  gx = dL/dx of the residual stream, in x[] ---------------------
+    {
+        const float* a = ab + 10 * 2 * ONET_H;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_WOUT + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[t][r] = relu_gate(mf, 4 * t + r, dl * w[r] * av[r]);
+        }
+    }
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+        const int gi = 10 + 2 * (4 - i);                                           // image index of fc_1[i]^T
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[4 * t + r] = x[t][r];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        layer_mfma(img, lds, gi * CHUNKS_PER_LAYER, wave, lane, u, acc);          // g_u2 = W1^T gx
+        {
+            const float* a = ab + (2 * i + 1) * 2 * ONET_H;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[4 * t + r] = relu_gate(m1[i], 4 * t + r, acc[t][r] * av[r]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        layer_mfma(img, lds, (gi + 1) * CHUNKS_PER_LAYER, wave, lane, u, acc);    // g_u = W0^T g_h
+        {
+            const float* a = ab + (2 * i) * 2 * ONET_H;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    x[t][r] += relu_gate(m0[i], 4 * t + r, acc[t][r] * av[r]);
+            }
+        }
+    }
+    // d/dp through fc_p
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_FCP + (16 * t + 4 * q + r) * 4);
+            g0 = fmaf(w.x, x[t][r], g0); g1 = fmaf(w.y, x[t][r], g1); g2 = fmaf(w.z, x[t][r], g2);
+        }
+    g0 = add_lane_xor32(add_lane_xor16(g0));
+    g1 = add_lane_xor32(add_lane_xor16(g1));
+    g2 = add_lane_xor32(add_lane_xor16(g2));
+    dx[0] = g0; dx[1] = g1; dx[2] = g2;
+}
+
+// per-cloud prologue: CBN a/b + the small parameters into LDS, first weight chunk in flight and landed
+__device__ __forceinline__ void onet_prologue(const float* __restrict__ img, const float* __restrict__ small,
+                                              const float* __restrict__ ab_cloud, float* __restrict__ lds, int tid, int nthreads,
+                                              int wave, int lane) {
+    for (int i = tid; i < ONET_NCBN * 2 * ONET_H; i += nthreads) lds[OL_AB + i] = ab_cloud[i];
+    for (int i = tid; i < ONET_SMALL_FLOATS; i += nthreads) lds[OL_FCP + i] = small[i];
+    stage_chunk(img, lds, 0, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split precision (PREC 1: bf16x6, f32-equivalent; PREC 2: bf16x3, reduced - split_bf16.h): the ten 256x256 layers of a pass on
+// v_mfma_f32_16x16x32_bf16 with three exact bf16 pieces per weight and per activation.
+//   * k-OUTER order: a chunk of the weight stream is ONE k-step (32 input channels) x 8 output tiles x 3 weight pieces = 24 KB;
+//     the eight input values a lane holds for that k-step are produced just in time (CBN, ReLU, mask bits or the backward gate),
+//     split into pieces (conversions on the vector ALU, residuals on the matrix pipe) and multiplied into all 16 output tiles - no
+//     64-register copy of the layer's input, no bf16 copy of it either (3 x 32 registers).
+//   * the accumulator layout is the f32 pass's: value k = 4 t + r of a lane = channel 16 t + 4 q + r; k-slot (g, j) of k-step s is
+//     value 8 s + j, so ReLU masks, CBN coefficients and the small parameters are shared with the f32 pass.
+//   * W0^T of the backward chain would need three 64-register arrays (its input, its output, the residual gradient): its image is
+//     ordered output-half-major and the layer runs as two sweeps over the k-steps into a 32-register half accumulator.
+//   * every A fragment (1 KB) feeds 3 (w1), 2 (w2), 1 (w3) MFMAs of 16 cycles: the LDS reads of a workgroup add up to the whole
+//     128 B / clk of the CU at the full MFMA rate - the kernel's bound.
+// ---------------------------------------------------------------------------------------------------------------------
+#include "split_bf16.h"
+
+constexpr int BCHUNK_BYTES = 8 * 3 * 1024;           // 8 output tiles x 3 pieces x (64 lanes x 16 B)
+constexpr int BCHUNKS_PER_LAYER = 16;                // 8 k-steps x 2 halves of the output tiles
+constexpr int BN_CHUNKS = N_IMG * BCHUNKS_PER_LAYER; // 320 per forward + backward pass
+static_assert(BCHUNK_BYTES <= CHUNK_FLOATS * 4, "the bf16 chunks use the f32 pass's two LDS chunk buffers");
+
+__device__ __forceinline__ void stage_chunk_bf(const float* __restrict__ img, float* __restrict__ lds, int g, int wave, int lane) {
+    // chunk g of the circular weight stream -> buffer g & 1; 24 pieces of 1 KiB, 3 per wave
+    const char* src = reinterpret_cast<const char*>(img) + (size_t)g * BCHUNK_BYTES + wave * 3072 + lane * 16;
+    char* dst = reinterpret_cast<char*>(lds + OL_CHUNK + (g & 1) * CHUNK_FLOATS) + wave * 3072;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+}
+
+// one chunk: o8[t8] += W[tile t8][k-step] x for the eight output tiles of the chunk resident in buffer `gc & 1`; stages chunk gn
+template <int PREC>
+__device__ __forceinline__ void chunk_mfma_bf(const float* __restrict__ img, float* __restrict__ lds, int gc, int gn, int wave, int lane,
+                                              const Pieces& P, f32x4* __restrict__ o8) {
+    constexpr int NP = PREC == 1 ? 3 : 2, NT = PREC == 1 ? 6 : 3;
+    constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TP6[6] = {0, 2, 1, 0, 1, 0};      // w3 x1, w1 x3, w2 x2, w2 x1, w1 x2, w1 x1
+    constexpr int TA3[3] = {1, 0, 0}, TP3[3] = {0, 1, 0};                        // w2 x1, w1 x2, w1 x1
+    stage_chunk_bf(img, lds, gn, wave, lane);                                    // prefetch the next chunk into the other buffer
+    const bf16x8* a = reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(lds + OL_CHUNK + (gc & 1) * CHUNK_FLOATS)) + lane;
+    bf16x8 f[2][2][3];                                                           // [buffer][tile of the pair][piece], one pair ahead
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) f[0][u][pc] = a[(u * 3 + pc) * 64];
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        if (tp + 1 < 4) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) f[(tp + 1) & 1][u][pc] = a[((2 * (tp + 1) + u) * 3 + pc) * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {                                           // two independent accumulator chains
+            const int ta = PREC == 1 ? TA6[k] : TA3[k], tx = PREC == 1 ? TP6[k] : TP3[k];
+            o8[2 * tp] = mfma_bf(f[tp & 1][0][ta], P.p[tx], o8[2 * tp]);
+            o8[2 * tp + 1] = mfma_bf(f[tp & 1][1][ta], P.p[tx], o8[2 * tp + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // my pieces of the next chunk have landed
+    __builtin_amdgcn_s_barrier();                                                // everybody's have, and everybody is done with this one
+}
+
+// a whole layer in k-outer order (chunk 2 s + h): out[16] += W src; src(s) returns the eight input values of k-step s
+template <int PREC, typename Src>
+__device__ __forceinline__ void layer_mfma_bf(const float* __restrict__ img, float* __restrict__ lds, int g, int wave, int lane,
+                                              const SelMat& sel, Src src, f32x4 (&out)[16]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        Pieces P;
+        split_bf<PREC>(src(s), sel, P);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int gc = g + 2 * s + h;
+            int gn = gc + 1;
+            if (gn >= BN_CHUNKS) gn -= BN_CHUNKS;
+            chunk_mfma_bf<PREC>(img, lds, gc, gn, wave, lane, P, &out[8 * h]);
+        }
+    }
+}
+// half a layer of an image stored output-half-major (chunk 8 h + s): o8[8] += W[tiles 8 h ... 8 h + 7] src
+template <int PREC, typename Src>
+__device__ __forceinline__ void layer_half_bf(const float* __restrict__ img, float* __restrict__ lds, int g, int h, int wave, int lane,
+                                              const SelMat& sel, Src src, f32x4 (&o8)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        Pieces P;
+        split_bf<PREC>(src(s), sel, P);
+        const int gc = g + 8 * h + s;
+        int gn = gc + 1;
+        if (gn >= BN_CHUNKS) gn -= BN_CHUNKS;
+        chunk_mfma_bf<PREC>(img, lds, gc, gn, wave, lane, P, &o8[0]);
+    }
+}
+
+// relu(a x + b) of the eight values of k-step s (values 8 s ... 8 s + 7 = registers r of tiles 2 s, 2 s + 1), mask bits appended
+__device__ __forceinline__ f32x8 cbn_relu8(const float* __restrict__ ab, int q, const f32x4 (&x)[16], int s, Mask64& m) {
+    f32x8 u;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * s + tt;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ab + 16 * t + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ab + ONET_H + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = fmaf(a[r], x[t][r], b[r]);
+            const int ri = max(__float_as_int(v), 0);
+            u[4 * tt + r] = __int_as_float(ri);
+            m.w[(4 * t + r) >> 5] = __builtin_amdgcn_alignbit(m.w[(4 * t + r) >> 5], (unsigned int)ri - 1u, 31);
+        }
+    }
+    return u;
+}
+
+template <int MODE, bool WANT_GRAD, int PREC>
+__device__ __forceinline__ void onet_pass_bf(const float* __restrict__ img, float* __restrict__ lds, int wave, int lane,
+                                             float x0, float x1, float x2, float threshold, float inv_lb, float& logit,
+                                             float& bce, float (&dx)[3]) {
+    const int q = lane >> 4;
+    const float* ab = lds + OL_AB;
+    const SelMat sel = make_selmat(lane);
+    f32x4 x[16], acc[16];
+    Mask64 m0[5], m1[5], mf = {{0u, 0u}};
+    // fc_p (decoder.py:118)
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_FCP + (16 * t + 4 * q + r) * 4);
+            x[t][r] = fmaf(w.z, x2, fmaf(w.y, x1, fmaf(w.x, x0, w.w)));
+        }
+    // five CResnetBlockConv1d (layers.py:97-107): x += fc_1(relu(bn_1(fc_0(relu(bn_0(x))))))
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        m0[i] = Mask64{{0u, 0u}};
+        m1[i] = Mask64{{0u, 0u}};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};          // fc_0 bias is folded into bn_1
+        layer_mfma_bf<PREC>(img, lds, (2 * i) * BCHUNKS_PER_LAYER, wave, lane, sel,
+                            [&](int s) { return cbn_relu8(ab + (2 * i) * 2 * ONET_H, q, x, s, m0[i]); }, acc);
+        asm("" : "+v"(m0[i].w[0]), "+v"(m0[i].w[1]));
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(lds + OL_B1 + i * ONET_H + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[t][r] = x[t][r] + b1[r];                 // (element by element: no packed f32 in this kernel)
+        }
+        layer_mfma_bf<PREC>(img, lds, (2 * i + 1) * BCHUNKS_PER_LAYER, wave, lane, sel,
+                            [&](int s) { return cbn_relu8(ab + (2 * i + 1) * 2 * ONET_H, q, acc, s, m1[i]); }, x);
+        asm("" : "+v"(m1[i].w[0]), "+v"(m1[i].w[1]));
+    }
+    // fc_out(relu(bn(x)))  (decoder.py:130)
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const f32x8 u = cbn_relu8(ab + 10 * 2 * ONET_H, q, x, s, mf);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_WOUT + 16 * (2 * s + tt) + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(w[r], u[4 * tt + r], part);
+        }
+    }
+    asm("" : "+v"(mf.w[0]), "+v"(mf.w[1]));
+    part = add_lane_xor32(add_lane_xor16(part));
+    logit = part + lds[OL_WOUT + ONET_H];
+    float dl;
+    if (MODE == OMODE_OPT) {
+        const float e = expf(-fabsf(logit));
+        bce = fmaxf(logit, 0.f) - logit * threshold + log1pf(e);
+        const float sig = logit >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        dl = (sig - threshold) * inv_lb;
+    } else {
+        bce = logit;
+        dl = 1.f;
+    }
+    dx[0] = dx[1] = dx[2] = 0.f;
+    if (!WANT_GRAD) {
+        // the next pass starts at chunk 0 again (the chunk the last layer staged is not read by anybody)
+        stage_chunk_bf(img, lds, 0, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    // ---- backward (parameters frozen: only d/dx).  gx = dL/dx of the residual stream, in x[] ---------------------
+    {
+        const float* a = ab + 10 * 2 * ONET_H;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + 16 * t + 4 * q);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_WOUT + 16 * t + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[t][r] = relu_gate(mf, 4 * t + r, dl * w[r] * av[r]);
+        }
+    }
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+        const int gi = 10 + 2 * (4 - i);                                           // image index of fc_1[i]^T
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        layer_mfma_bf<PREC>(img, lds, gi * BCHUNKS_PER_LAYER, wave, lane, sel,                       // g_u2 = W1^T gx
+                            [&](int s) { return f32x8{x[2 * s][0], x[2 * s][1], x[2 * s][2], x[2 * s][3],
+                                                      x[2 * s + 1][0], x[2 * s + 1][1], x[2 * s + 1][2], x[2 * s + 1][3]}; }, acc);
+        // g_h = gate(m1, g_u2 a_1), made per k-step inside the next layer; g_u = W0^T g_h in two sweeps (output halves)
+        const float* a1 = ab + (2 * i + 1) * 2 * ONET_H;
+        const float* a0 = ab + (2 * i) * 2 * ONET_H;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 half[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) half[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            layer_half_bf<PREC>(img, lds, (gi + 1) * BCHUNKS_PER_LAYER, h, wave, lane, sel,
+                                [&](int s) {
+                                    f32x8 u;
+#pragma unroll
+                                    for (int tt = 0; tt < 2; ++tt) {
+                                        const int t = 2 * s + tt;
+                                        const f32x4 av = *reinterpret_cast<const f32x4*>(a1 + 16 * t + 4 * q);
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) u[4 * tt + r] = relu_gate(m1[i], 4 * t + r, acc[t][r] * av[r]);
+                                    }
+                                    return u;
+                                }, half);
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) {
+                const int t = 8 * h + t8;
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + 16 * t + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[t][r] = x[t][r] + relu_gate(m0[i], 4 * t + r, half[t8][r] * av[r]);
+            }
+        }
+    }
+    // d/dp through fc_p
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + OL_FCP + (16 * t + 4 * q + r) * 4);
+            g0 = fmaf(w.x, x[t][r], g0); g1 = fmaf(w.y, x[t][r], g1); g2 = fmaf(w.z, x[t][r], g2);
+        }
+    g0 = add_lane_xor32(add_lane_xor16(g0));
+    g1 = add_lane_xor32(add_lane_xor16(g1));
+    g2 = add_lane_xor32(add_lane_xor16(g2));
+    dx[0] = g0; dx[1] = g1; dx[2] = g2;
+}
+
+// per-cloud prologue of the split-precision kernels (as onet_prologue; chunk 0 of the bf16 image)
+__device__ __forceinline__ void onet_prologue_bf(const float* __restrict__ img, const float* __restrict__ small,
+                                                 const float* __restrict__ ab_cloud, float* __restrict__ lds, int tid, int nthreads,
+                                                 int wave, int lane) {
+    for (int i = tid; i < ONET_NCBN * 2 * ONET_H; i += nthreads) lds[OL_AB + i] = ab_cloud[i];
+    for (int i = tid; i < ONET_SMALL_FLOATS; i += nthreads) lds[OL_FCP + i] = small[i];
+    stage_chunk_bf(img, lds, 0, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+constexpr size_t ONET_DEC_LDS = (size_t)OL_END * 4;
+constexpr int OL_G = OL_END;                                        // optimiser state behind the decoder's
+constexpr size_t ONET_OPT_LDS = ONET_DEC_LDS + MAXK * 16 * 2 + 16 + MAXK * 12 + 128 * 4;
+static_assert(ONET_OPT_LDS <= 160 * 1024, "LDS budget");
+
+// The ONet-Opt optimiser (ONet/opt_defense.py:182-239): same skeleton as optimize_kernel, decoder passes instead
+// of plane tiles.  The kNN phase is ~1 % of a step here, so all waves simply run it first.
+template <int PREC>        // 0: f32 MFMAs (img = the f32 fragment image); 1 / 2: bf16x6 / bf16x3 (img = the bf16 piece image)
+__global__ __launch_bounds__(OPT_THREADS, 2) void onet_optimize_kernel(
+    const float* __restrict__ img, const float* __restrict__ small, const float* __restrict__ ab, float* __restrict__ p,
+    float* __restrict__ m_io, float* __restrict__ v_io, float* __restrict__ loss_out,
+    const int32_t* __restrict__ loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* __restrict__ counters,
+    const float* __restrict__ adam_tab, int K, OptArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* G = reinterpret_cast<f32x4*>(smem + OL_G);                // occupancy gradient (+ BCE term in .w)
+    f32x4* X = G + MAXK;                                             // current points; X[MAXK] = far-away dummy
+    const RepAcc F = {reinterpret_cast<long long*>(X + MAXK + 1),    // fixed-point repulsion-gradient scatter (knn_device.h)
+                      reinterpret_cast<int*>(reinterpret_cast<long long*>(X + MAXK + 1) + MAXK)};
+    float* scratch = reinterpret_cast<float*>(F.z + MAXK);           // 128 floats
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pc = p + (size_t)cloud * K * 3;
+    const int pa = tid, pb = tid + OPT_THREADS;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+
+    AdamState ast;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pt = q ? pb : pa;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ast.mm[3 * q + a] = ast.vv[3 * q + a] = 0.f;
+        if (pt < K) {
+            X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
+            if (A.t0 > 0 && m_io != nullptr) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    ast.mm[3 * q + a] = m_io[((size_t)cloud * K + pt) * 3 + a];
+                    ast.vv[3 * q + a] = v_io[((size_t)cloud * K + pt) * 3 + a];
+                }
+            }
+        }
+    }
+    for (int i = tid; i < MAXK; i += OPT_THREADS) { F.xy[i] = 0; F.z[i] = 0; }
+    if (tid == 0) X[MAXK] = f32x4{1e18f, 1e18f, 1e18f, 0.f};
+
+    const RepConst rc = {A.rep_radius, A.rep_h, A.rep_eps};
+    const int loss_batch = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : A.loss_batch;
+    const float inv_lb = 1.0f / (float)loss_batch;
+    const float rep_scale = A.rep_weight / ((float)loss_batch * (float)K * 5.f);
+    const bool use_rep = A.rep_weight > 0.f;
+    float rep_loss_a = 0.f, rep_loss_b = 0.f;
+    uint16_t* La = knn_lists + ((size_t)cloud * MAXK + (pa & (MAXK - 1))) * LIST_M;
+    uint16_t* Lb = knn_lists + ((size_t)cloud * MAXK + (pb & (MAXK - 1))) * LIST_M;
+    KnnPt ka = {0, -1, 0.f, 0.f, 2.0f, 7.0f, f32x4{0.f, 0.f, 0.f, 0.f}, 0.f, 0.f, false, false};
+    KnnPt kb = ka;
+    uint16_t* cloud_lists = knn_lists + (size_t)cloud * MAXK * LIST_M;
+    float* dmaxbuf = scratch + 32;
+    float* movebuf = scratch + 64;
+    volatile int* rebuild_flag = reinterpret_cast<volatile int*>(scratch + 28);
+    unsigned int* lcnt = reinterpret_cast<unsigned int*>(scratch + 96);           // [CN_COUNT] event counters
+    KnnCounters cn{lcnt, lane};
+    const KnnShared ksh = {dmaxbuf, movebuf, rebuild_flag};
+    if (tid < 2) rebuild_flag[tid] = 0;
+    if (tid < CN_COUNT) lcnt[tid] = 0u;
+    if (tid < 2 * MAX_WAVES) { dmaxbuf[tid] = 0.f; movebuf[tid] = 2.f * A.lr; }
+    if constexpr (PREC == 0) onet_prologue(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);   // syncs
+    else onet_prologue_bf(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);
+
+    const int npass = (K + 127) >> 7;
+    for (int step = 0; step < A.steps; ++step) {
+        const bool last = step == A.steps - 1;
+        if (use_rep)
+            knn_phase(X, F, K, pa, pb, wave, lane, step, last, A.knn_scan_every_step, La, Lb, cloud_lists, ka, kb, ksh,
+                      rc, rep_loss_a, rep_loss_b, cn);
+#pragma unroll 1
+        for (int g = 0; g < npass; ++g) {
+            const int pt = g * 128 + wave * 16 + (lane & 15), tp = min(pt, K - 1);
+            const f32x4 x = X[tp];
+            float logit, bce, dx[3];
+            if constexpr (PREC == 0) onet_pass<OMODE_OPT, true>(img, smem, wave, lane, x.x, x.y, x.z, A.threshold, inv_lb, logit, bce, dx);
+            else onet_pass_bf<OMODE_OPT, true, PREC == 0 ? 1 : PREC>(img, smem, wave, lane, x.x, x.y, x.z, A.threshold, inv_lb, logit, bce, dx);
+            if (lane < 16 && pt < K) G[tp] = f32x4{dx[0], dx[1], dx[2], bce};
+        }
+        __syncthreads();
+        if (last && loss_out != nullptr) {   // losses at the pre-update points of the last step
+            float occ = (pa < K ? G[pa].w : 0.f) + (pb < K ? G[pb].w : 0.f);
+            float rep = (pa < K ? rep_loss_a : 0.f) + (pb < K ? rep_loss_b : 0.f);
+            occ = wave_sum(occ);
+            rep = wave_sum(rep);
+            if (lane == 0) { scratch[wave] = occ; scratch[MAX_WAVES + wave] = rep; }
+            __syncthreads();
+            if (tid == 0) {
+                float so = 0.f, sr = 0.f;
+                for (int w = 0; w < OPT_THREADS / 64; ++w) { so += scratch[w]; sr += scratch[MAX_WAVES + w]; }
+                loss_out[2 * cloud + 0] = so;
+                loss_out[2 * cloud + 1] = sr / ((float)K * 5.f);
+            }
+        }
+        float xnew[2][3], mv2;
+        adam_phase(X, G, F, K, pa, pb, adam_tab[2 * step], adam_tab[2 * step + 1], rep_scale, ast, xnew, mv2, counters);
+        adam_displacement(K, pa, pb, wave, lane, step, xnew, mv2, ka, kb, ksh);
+        if (tid == 0) rebuild_flag[step & 1] = 0;
+        __syncthreads();
+    }
+
+    if (counters != nullptr) {
+        if (tid < CN_COUNT) {
+            constexpr int SLOT[CN_COUNT] = {0, 1, 2, 4, 5, 6, 7};
+            atomicAdd(counters + SLOT[tid], (unsigned long long)lcnt[tid]);
+        }
+        if (tid == 0 && cloud == 0) counters[3] = __builtin_readcyclecounter() - t_begin;
+    }
+    if (A.normalize) normalize_in_lds(X, K, scratch);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pt = q ? pb : pa;
+        if (pt < K) {
+            const f32x4 x = X[pt];
+            pc[3 * pt] = x.x; pc[3 * pt + 1] = x.y; pc[3 * pt + 2] = x.z;
+            if (m_io != nullptr) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    m_io[((size_t)cloud * K + pt) * 3 + a] = ast.mm[3 * q + a];
+                    v_io[((size_t)cloud * K + pt) * 3 + a] = ast.vv[3 * q + a];
+                }
+            }
+        }
+    }
+}
+

@@ -45,11 +45,10 @@ def build_parser(model="convonet"):
     parser.add_argument('--printing', type=str2bool, default=False,
                         help='print the losses every 100 iterations like the reference does (opt_defense.py:229-236; '
                              'off by default: every print is a device synchronisation)')
-    if model == "convonet":
-        parser.add_argument('--precision', choices=('f32', 'bf16x6', 'bf16x3'), default='f32',
-                            help="arithmetic of the decoder's dense layers in the optimiser (opt-in extension; default f32 = the "
-                                 "reference's): bf16x6 = six bf16 products of exact three-piece splits, f32-equivalent, ~1.2x faster; "
-                                 "bf16x3 = three products, 2^-17 relative: REDUCED precision, ~1.4x faster")
+    parser.add_argument('--precision', choices=('f32', 'bf16x6', 'bf16x3'), default='f32',
+                        help="arithmetic of the decoder's dense layers in the optimiser (opt-in extension; default f32 = the "
+                             "reference's): bf16x6 = six bf16 products of exact three-piece splits, f32-equivalent (ConvONet ~1.2x, "
+                             "ONet ~1.7x faster); bf16x3 = three products, 2^-17 relative: REDUCED precision (~1.4x / ~2.7x)")
     return parser
 
 

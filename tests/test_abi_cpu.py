@@ -247,8 +247,15 @@ def test_split_precision_kernels_contain_no_packed_f32_instruction(lib, tmp_path
             body = body[:body.index("s_endpgm")]
             found[sym] = (len(re.findall(r"\bv_pk_(?:mul|fma|add)_f32\b", body)), len(re.findall(r"\bv_mfma_f32_16x16x32_bf16\b", body)))
     assert len(found) == 9, sorted(found)
+    # the ONet-Opt optimiser likewise (onet.hip: <0>, onet_bf.hip: <1>, <2>)
+    for txt in _disassemblies(I.LIB_PATH, tmp_path):
+        for sym in sorted(set(re.findall(r"<_ZN3ifd20(onet_optimize_kernelILi[012]E)", txt))):
+            body = txt[txt.index("<_ZN3ifd20" + sym):]
+            body = body[:body.index("s_endpgm")]
+            found[sym] = (len(re.findall(r"\bv_pk_(?:mul|fma|add)_f32\b", body)), len(re.findall(r"\bv_mfma_f32_16x16x32_bf16\b", body)))
+    assert len(found) == 12, sorted(found)
     for sym, (n_pk, n_bf) in found.items():
         if sym.endswith("Li0E"):
-            assert n_bf == 0 and n_pk > 0, (sym, n_pk, n_bf)         # the f32 kernels: packed f32 is fine beside f32 MFMAs (and used)
+            assert n_bf == 0 and (n_pk > 0 or sym.startswith("onet")), (sym, n_pk, n_bf)     # the f32 kernels: packed f32 is fine beside f32 MFMAs
         else:
             assert n_bf > 100 and n_pk == 0, (sym, n_pk, n_bf)
