@@ -1,0 +1,27 @@
+"""ifd_optimize on clouds of more than 1024 points (the two-launch-per-step path): time per point and step against the persistent kernel."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import ifdefense_amd as I  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ks = [int(a) for a in sys.argv[2:]] or [1024, 2048]
+r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device="cuda:0")
+x = torch.from_numpy(bench.synth_clouds(n)).cuda()
+base = None
+for k in ks:
+    steps = 51 if k <= 1024 else 11
+    prep = r.prepare(x, r.sor(x), n_sel=600, n_opt=k, seed=1234)
+    planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+    r.optimize_points(prep["init"][:8], planes[:8], rep_weight=500.0, steps=2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    per = dt / (n * k * steps)
+    base = base or per
+    print("K = %5d: %d clouds x %d steps in %.1f ms -> %.2f ns per point and step (%.2f x the first line)" % (k, n, steps, dt * 1e3, per * 1e9, per / base))
