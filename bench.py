@@ -454,6 +454,16 @@ def extras(dev):
                             "what": "ifd_onet_mesh_sample, 64 clouds, 32 -> 128 MISE grid, iso-surface at the field's median; "
                                     "roofline_frac = decoder FLOPs of the evaluated grid points / WHOLE-path time / f32-MFMA peak "
                                     "(onet_grid_eval_kernel alone: profiles/r05_onet_mesh_kernel_stats.txt)"}
+        spm = {}
+        for mode in ("bf16x6", "bf16x3"):     # ifd_mesh_params.precision: the grid evaluation on the split-precision passes (opt-in)
+            r.mesh_sample(c[:4], threshold=thr, precision=mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.mesh_sample(c[:64], threshold=thr, precision=mode)
+            torch.cuda.synchronize()
+            spm[mode] = {"value": round(64 / (time.perf_counter() - t0), 1), "unit": "clouds/s",
+                         "precision": "f32-equivalent" if mode == "bf16x6" else "REDUCED (2^-17 relative per product)"}
+        out["onet_mesh"]["split_precision"] = spm
         r.close()
     except Exception as e:      # noqa: BLE001
         out["onet"] = {"error": str(e)[:200]}

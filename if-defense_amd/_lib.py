@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("IFD_LIB") or os.path.join(HERE, "csrc", "libifd.so")
 IFD_OK = 0
 IFD_ERR_TIMEOUT = -5
 IFD_ERR_OVERFLOW = -6
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class IfdConfig(C.Structure):
@@ -40,7 +40,7 @@ class IfdPrepParams(C.Structure):
 class IfdMeshParams(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("resolution0", C.c_int32), ("upsampling_steps", C.c_int32),
                 ("n_sample", C.c_int32), ("max_triangles", C.c_int32), ("padding", C.c_float), ("threshold", C.c_double),
-                ("seed", C.c_uint64), ("cloud_index_base", C.c_int64)]
+                ("seed", C.c_uint64), ("cloud_index_base", C.c_int64), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/ifd.h declares (tests check this)

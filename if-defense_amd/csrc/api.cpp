@@ -969,8 +969,8 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
         return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: bad argument");
     const int depth = prm->upsampling_steps, res0 = prm->resolution0;
     if (depth < 0 || depth > 2 || res0 < 2 || (res0 << depth) > 128 || prm->n_sample < 1 || prm->max_triangles < 1 ||
-        !(prm->threshold > 0.0 && prm->threshold < 1.0))
-        return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: resolution0 << upsampling_steps <= 128, steps <= 2, 0 < threshold < 1");
+        !(prm->threshold > 0.0 && prm->threshold < 1.0) || prm->precision < 0 || prm->precision > 2)
+        return fail(ctx, IFD_ERR_ARG, "ifd_onet_mesh_sample: resolution0 << upsampling_steps <= 128, steps <= 2, 0 < threshold < 1, precision 0 ... 2");
     hipStream_t s = static_cast<hipStream_t>(stream);
     MiseGrid g{};
     g.res0 = res0; g.depth = depth; g.P = (res0 << depth) + 1; g.P3 = g.P * g.P * g.P;
@@ -1043,7 +1043,8 @@ int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_par
         int round = 0;
         for (; round < 64 && !done; ++round) {
             int* slot = ctx->h_mesh_counts + (size_t)(round & 1) * ctx->h_mesh_counts_n;
-            e = launch_onet_grid_eval(ctx->d_onet_img, ctx->d_onet_small, ab, g, nb, ctx->n_cu, box, s);
+            e = prm->precision != 0 ? launch_onet_grid_eval_bf(prm->precision, ctx->d_onet_img_bf, ctx->d_onet_small, ab, g, nb, ctx->n_cu, box, s)
+                                    : launch_onet_grid_eval(ctx->d_onet_img, ctx->d_onet_small, ab, g, nb, ctx->n_cu, box, s);
             if (e == hipSuccess) e = launch_mise_update(g, nb, s);
             if (e == hipSuccess) e = hipMemcpyAsync(slot, g.count, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipEventRecord(ctx->mesh_ev[round & 1], s);

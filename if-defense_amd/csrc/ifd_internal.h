@@ -151,6 +151,8 @@ hipError_t launch_mise_update(const MiseGrid& g, int B, hipStream_t s);
 hipError_t launch_mise_fill(const MiseGrid& g, int B, hipStream_t s);
 hipError_t launch_onet_grid_eval(const float* img, const float* small, const float* ab, const MiseGrid& g, int B,
                                  int n_blocks, float box, hipStream_t s);
+hipError_t launch_onet_grid_eval_bf(int precision, const float* img_bf, const float* small, const float* ab, const MiseGrid& g, int B,
+                                    int n_blocks, float box, hipStream_t s);
 hipError_t mc_upload_table();
 void mc_host_table(int8_t (*tri)[16], uint8_t* ntri);
 hipError_t launch_marching_cubes(const float* val, int B, int P, double iso, float box, int* cube_offs, int* ntri_total,

@@ -215,83 +215,17 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_decode_kernel(const float
     }
 }
 
-// Occupancy at the queued grid points of the MISE rounds (mesh.hip; generation.py:112-127 eval_points), forward only.
-// DEVICE-DRIVEN (round 5): the host does not know the queue lengths.  grid_plan_kernel turns the clouds' counts into an exclusive
-// prefix of 128-point decoder passes; the evaluation kernel is a fixed launch of one workgroup per CU (98 KB of LDS: one fits),
-// workgroup j takes the contiguous range [j T / G, (j + 1) T / G) of the round's T passes - whatever cloud they belong to; the
-// cloud's folded CBN coefficients are re-read into LDS when the range crosses into the next cloud.  Rounds 1-4 launched
-// (segment of 2048 points, cloud) blocks sized by a max count the host read back every round: a round of e.g. 1152 blocks on 256
-// CUs ran as 4.5 waves of 5 ms each and the last wave was half empty (onet_grid_eval_kernel 0.72 of the f32-MFMA peak against
-// 0.86 for the optimiser's passes on the same code).
-__global__ void grid_plan_kernel(MiseGrid g, int B) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int acc = 0;
-    for (int b = 0; b < B; ++b) {
-        g.plan[b] = acc;
-        acc += (min(g.count[b], g.cap) + 127) >> 7;
-    }
-    g.plan[B] = acc;
-}
-
-__global__ __launch_bounds__(OPT_THREADS, 2) void onet_grid_eval_kernel(const float* __restrict__ img, const float* __restrict__ small,
-                                                                         const float* __restrict__ ab, MiseGrid g, int B, float box) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long T = g.plan[B];
-    int pass = (int)((T * blockIdx.x) / gridDim.x);
-    const int pass_end = (int)((T * (blockIdx.x + 1)) / gridDim.x);
-    if (pass >= pass_end) return;                                              // block-uniform
-    // the cloud of the first pass: largest b with plan[b] <= pass (clouds without points have empty ranges and are stepped over)
-    int lo = 0, hi = B - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (g.plan[mid] <= pass) lo = mid; else hi = mid - 1;
-    }
-    int cloud = lo;
-    const float inv_r = (float)(g.P - 1);
-    bool first = true;
-    while (pass < pass_end) {
-        while (g.plan[cloud + 1] <= pass) ++cloud;                             // (uniform; at most B steps over the whole range)
-        const float* abc = ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H;
-        if (first) {
-            onet_prologue(img, small, abc, smem, tid, OPT_THREADS, wave, lane);
-            first = false;
-        } else {
-            // every wave has left the previous cloud's last pass (it ends in a workgroup barrier): replace the CBN block only
-            for (int i = tid; i < ONET_NCBN * 2 * ONET_H; i += OPT_THREADS) smem[OL_AB + i] = abc[i];
-            __syncthreads();
-        }
-        const int n = min(g.count[cloud], g.cap);
-        const int* list = g.list + (size_t)cloud * g.cap;
-        const int stop = min(pass_end, g.plan[cloud + 1]);
-        for (; pass < stop; ++pass) {
-            const int base = (pass - g.plan[cloud]) * 128;
-            const int i = base + wave * 16 + (lane & 15);
-            const int idx = list[min(i, n - 1)];
-            const int x = idx / (g.P * g.P), y = (idx / g.P) % g.P, z = idx % g.P;
-            // pointsf / resolution, box_size * (pointsf - 0.5) in float32 (generation.py:117-121)
-            const float px = ((float)x / inv_r - 0.5f) * box, py = ((float)y / inv_r - 0.5f) * box, pz = ((float)z / inv_r - 0.5f) * box;
-            float logit, bce, dx[3];
-            onet_pass<OMODE_SUM, false>(img, smem, wave, lane, px, py, pz, 0.f, 1.f, logit, bce, dx);
-            if (lane < 16 && i < n) {
-                g.val[(size_t)cloud * g.P3 + idx] = logit;
-                g.known[(size_t)cloud * g.P3 + idx] = 1;
-            }
-        }
-    }
-}
-
 hipError_t launch_onet_grid_eval(const float* img, const float* small, const float* ab, const MiseGrid& g, int B, int n_blocks,
                                  float box, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL(grid_plan_kernel, dim3(1), dim3(64), 0, s, g, B);
-    hipLaunchKernelGGL(onet_grid_eval_kernel, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, g, B, box);
+    hipLaunchKernelGGL(grid_plan_kernel<0>, dim3(1), dim3(64), 0, s, g, B);
+    hipLaunchKernelGGL(onet_grid_eval_kernel<0>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, g, B, box);
     return hipGetLastError();
 }
 

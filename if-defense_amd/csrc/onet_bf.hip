@@ -19,6 +19,26 @@ hipError_t configure_onet_bf_kernels() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);
 }
 
+hipError_t launch_onet_grid_eval_bf(int precision, const float* img_bf, const float* small, const float* ab, const MiseGrid& g, int B,
+                                    int n_blocks, float box, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(grid_plan_kernel<1>, dim3(1), dim3(64), 0, s, g, B);
+    if (precision == 1)
+        hipLaunchKernelGGL(onet_grid_eval_kernel<1>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, g, B, box);
+    else
+        hipLaunchKernelGGL(onet_grid_eval_kernel<2>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, g, B, box);
+    return hipGetLastError();
+}
+
 hipError_t launch_onet_optimize_bf(int precision, const float* img_bf, const float* small, const float* ab, float* p, float* m, float* v,
                                    float* loss, const int32_t* loss_batch_per_cloud, uint16_t* knn_lists, unsigned long long* counters,
                                    const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {

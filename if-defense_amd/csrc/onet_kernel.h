@@ -490,6 +490,77 @@ constexpr int OL_G = OL_END;                                        // optimiser
 constexpr size_t ONET_OPT_LDS = ONET_DEC_LDS + MAXK * 16 * 2 + 16 + MAXK * 12 + 128 * 4;
 static_assert(ONET_OPT_LDS <= 160 * 1024, "LDS budget");
 
+// Occupancy at the queued grid points of the MISE rounds (mesh.hip; generation.py:112-127 eval_points), forward only.
+// DEVICE-DRIVEN (round 5): the host does not know the queue lengths.  grid_plan_kernel turns the clouds' counts into an exclusive
+// prefix of 128-point decoder passes; the evaluation kernel is a fixed launch of one workgroup per CU (98 KB of LDS: one fits),
+// workgroup j takes the contiguous range [j T / G, (j + 1) T / G) of the round's T passes - whatever cloud they belong to; the
+// cloud's folded CBN coefficients are re-read into LDS when the range crosses into the next cloud.  Rounds 1-4 launched
+// (segment of 2048 points, cloud) blocks sized by a max count the host read back every round: a round of e.g. 1152 blocks on 256
+// CUs ran as 4.5 waves of 5 ms each and the last wave was half empty (onet_grid_eval_kernel 0.72 of the f32-MFMA peak against
+// 0.86 for the optimiser's passes on the same code).
+template <int TU>           // (a template only so that both translation units that include this header may instantiate it)
+__global__ void grid_plan_kernel(MiseGrid g, int B) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        g.plan[b] = acc;
+        acc += (min(g.count[b], g.cap) + 127) >> 7;
+    }
+    g.plan[B] = acc;
+}
+
+template <int PREC>        // 0: f32 passes; 1 / 2: the split-precision passes (img = the bf16 piece image), ifd_mesh_params.precision
+__global__ __launch_bounds__(OPT_THREADS, 2) void onet_grid_eval_kernel(const float* __restrict__ img, const float* __restrict__ small,
+                                                                         const float* __restrict__ ab, MiseGrid g, int B, float box) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long T = g.plan[B];
+    int pass = (int)((T * blockIdx.x) / gridDim.x);
+    const int pass_end = (int)((T * (blockIdx.x + 1)) / gridDim.x);
+    if (pass >= pass_end) return;                                              // block-uniform
+    // the cloud of the first pass: largest b with plan[b] <= pass (clouds without points have empty ranges and are stepped over)
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (g.plan[mid] <= pass) lo = mid; else hi = mid - 1;
+    }
+    int cloud = lo;
+    const float inv_r = (float)(g.P - 1);
+    bool first = true;
+    while (pass < pass_end) {
+        while (g.plan[cloud + 1] <= pass) ++cloud;                             // (uniform; at most B steps over the whole range)
+        const float* abc = ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H;
+        if (first) {
+            if constexpr (PREC == 0) onet_prologue(img, small, abc, smem, tid, OPT_THREADS, wave, lane);
+            else onet_prologue_bf(img, small, abc, smem, tid, OPT_THREADS, wave, lane);
+            first = false;
+        } else {
+            // every wave has left the previous cloud's last pass (it ends in a workgroup barrier): replace the CBN block only
+            for (int i = tid; i < ONET_NCBN * 2 * ONET_H; i += OPT_THREADS) smem[OL_AB + i] = abc[i];
+            __syncthreads();
+        }
+        const int n = min(g.count[cloud], g.cap);
+        const int* list = g.list + (size_t)cloud * g.cap;
+        const int stop = min(pass_end, g.plan[cloud + 1]);
+        for (; pass < stop; ++pass) {
+            const int base = (pass - g.plan[cloud]) * 128;
+            const int i = base + wave * 16 + (lane & 15);
+            const int idx = list[min(i, n - 1)];
+            const int x = idx / (g.P * g.P), y = (idx / g.P) % g.P, z = idx % g.P;
+            // pointsf / resolution, box_size * (pointsf - 0.5) in float32 (generation.py:117-121)
+            const float px = ((float)x / inv_r - 0.5f) * box, py = ((float)y / inv_r - 0.5f) * box, pz = ((float)z / inv_r - 0.5f) * box;
+            float logit, bce, dx[3];
+            if constexpr (PREC == 0) onet_pass<OMODE_SUM, false>(img, smem, wave, lane, px, py, pz, 0.f, 1.f, logit, bce, dx);
+            else onet_pass_bf<OMODE_SUM, false, PREC == 0 ? 1 : PREC>(img, smem, wave, lane, px, py, pz, 0.f, 1.f, logit, bce, dx);
+            if (lane < 16 && i < n) {
+                g.val[(size_t)cloud * g.P3 + idx] = logit;
+                g.known[(size_t)cloud * g.P3 + idx] = 1;
+            }
+        }
+    }
+}
+
+
 // The ONet-Opt optimiser (ONet/opt_defense.py:182-239): same skeleton as optimize_kernel, decoder passes instead
 // of plane tiles.  The kNN phase is ~1 % of a step here, so all waves simply run it first.
 template <int PREC>        // 0: f32 MFMAs (img = the f32 fragment image); 1 / 2: bf16x6 / bf16x3 (img = the bf16 piece image)

@@ -390,10 +390,11 @@ class OnetRestorer(Restorer):
 
     def mesh_sample(self, c: torch.Tensor, n_sample: int = 1024, resolution0: int = 32, upsampling_steps: int = 2,
                     padding: float = 0.1, seed: int = 0, cloud_index_base: int = 0, max_triangles: int = 400000,
-                    want_grid: bool = False, want_triangles: bool = False, threshold: Optional[float] = None):
+                    want_grid: bool = False, want_triangles: bool = False, threshold: Optional[float] = None, precision=None):
         """reconstruct_mesh + trimesh.sample.sample_surface (ONet/remesh_defense.py:128-157) for a batch of latent codes:
         c [B,512] -> dict(points [B,n_sample,3] (not normalised), n_triangles [B] int32, optionally grid [B,P,P,P] and
-        triangles [B,max_triangles,9])."""
+        triangles [B,max_triangles,9]).  ``precision``: arithmetic of the grid evaluation's decoder layers (ifd_mesh_params.precision,
+        "f32" default / "bf16x6" / "bf16x3")."""
         c = self._cond(c)
         B = c.shape[0]
         P = (resolution0 << upsampling_steps) + 1
@@ -403,7 +404,7 @@ class OnetRestorer(Restorer):
         tris = torch.zeros(B, max_triangles, 9, device=self.device, dtype=torch.float32) if want_triangles else None
         prm = IfdMeshParams(C.sizeof(IfdMeshParams), int(resolution0), int(upsampling_steps), int(n_sample), int(max_triangles),
                             float(padding), float(self.threshold if threshold is None else threshold), int(seed),
-                            int(cloud_index_base))
+                            int(cloud_index_base), precision_code(precision), 0)
         with torch.cuda.device(self.device):
             self._check(self.lib.ifd_onet_mesh_sample(self.ctx, c.data_ptr(), B, C.byref(prm), pts.data_ptr(), ntri.data_ptr(),
                                                       self._ptr(grid), self._ptr(tris), self._stream()))

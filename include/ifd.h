@@ -51,7 +51,8 @@ extern "C" {
 
 /* 2: ifd_opt_params grew (split, planes_shared - round 3), ifd_optimize_status and the two status codes below were added */
 /* 3: ifd_opt_params.precision (round 5) */
-#define IFD_ABI_VERSION 3
+/* 4: ifd_mesh_params.precision (round 5) */
+#define IFD_ABI_VERSION 4
 
 enum {
     IFD_OK = 0,
@@ -319,6 +320,10 @@ typedef struct ifd_mesh_params {
     double threshold;          /* cfg test.threshold (0.2), as a probability; the iso-value is its logit */
     uint64_t seed;
     int64_t cloud_index_base;
+    int32_t precision;         /* arithmetic of the decoder layers in the grid evaluation, as ifd_opt_params.precision: 0 = f32 (default; the
+                                  grid is bit-identical to the reference's MISE class on the same decoder values), 1 = bf16x6 (f32-equivalent
+                                  values; a grid point within rounding of the threshold may fall on the other side), 2 = bf16x3 (reduced) */
+    int32_t reserved;          /* 0 */
 } ifd_mesh_params;
 
 int ifd_onet_mesh_sample(ifd_ctx* ctx, const float* c, int B, const ifd_mesh_params* prm, float* points,

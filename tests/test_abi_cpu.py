@@ -51,7 +51,7 @@ def test_exports_are_c_abi():
 
 def test_abi_version_and_weight_count(lib):
     from ifdefense_amd import weights
-    assert lib.ifd_abi_version() == 3
+    assert lib.ifd_abi_version() == 4
     n = sum(int(np.prod(s)) for _, s in weights.canonical_keys())
     assert n == 16001 + 27232 + 1934976 == lib.ifd_weight_count()
 

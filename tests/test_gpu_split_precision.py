@@ -10,6 +10,8 @@ of the decoder (ConvONet/src/conv_onet/models/decoder.py:83-93) on the bf16 matr
 A point whose gradient differs from the reference by more than the bar must be a ReLU boundary inside f32 rounding (category R of
 tests/test_gpu_parity.py's attribution protocol): nudging the point by <= 512 ulps makes the ORACLE's own gradient jump by the same
 amount.  Within a mode the kernel-level invariants hold bitwise: run to run, split clouds, certified lists vs exact scan."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -263,3 +265,46 @@ def test_onet_split_precision_against_reference_fixtures():
                            onet.optimize_points(pl, c[:1], rep_weight=500.0, iterations=3))
     finally:
         onet.close()
+
+
+def test_onet_mesh_split_precision():
+    """ifd_mesh_params.precision (round 5): the MISE grid evaluated with the split-precision decoder passes (forward only).  The f32 grid is
+    the one pinned bit for bit against the reference's MISE class (test_gpu_parity.py); here the other modes are held against it: logits on
+    the shared grid points, the number of evaluated points and triangles, and the surface samples as a distribution."""
+    import ifdefense_amd as I
+    sys_path_bench = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path_bench)
+    import bench
+    r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device="cuda:0")
+    try:
+        x = torch.from_numpy(bench.synth_clouds(6)).cuda()
+        prep = r.prepare(x, r.sor(x), n_sel=300, seed=1)
+        c = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+        g = torch.Generator().manual_seed(9)
+        med = float(r.decode((torch.rand(6, 4096, 3, generator=g) - 0.5) * 1.1, c).median())
+        thr = 1.0 / (1.0 + np.exp(-med))                         # random weights: cut the field at its median so that there is a surface
+        out, pts = {}, {}
+        for mode in MODES:
+            o = r.mesh_sample(c, threshold=thr, want_grid=True, precision=mode, seed=3)
+            out[mode] = (o["grid"].cpu().numpy(), o["n_triangles"].cpu().numpy(), o["points"].cpu().numpy())
+            pts[mode] = r.counters()["mesh_points"]
+        g32, n32, p32 = out["f32"]
+        scale = np.abs(g32[np.abs(g32) < 1e5]).max()
+        for mode in ("bf16x6", "bf16x3"):
+            gm, nm, pm = out[mode]
+            d = np.abs(gm - g32) / scale
+            frac_same = float((d < (1e-5 if mode == "bf16x6" else 1e-4)).mean())
+            dn = np.abs(nm.astype(np.int64) - n32) / np.maximum(n32, 1)
+            # samples: nearest-neighbour distance from this mode's samples to the f32 run's (same seed: same triangles picked unless the soup changed)
+            nn = np.sqrt(((pm[:, :, None, :] - p32[:, None, :, :]) ** 2).sum(-1)).min(-1)
+            print("ONet-Mesh %-7s: grid values within the bar of the f32 grid %.4f, max difference %.2e of max; evaluated points %d vs %d; triangles "
+                  "differ by <= %.4f; samples to the f32 samples: median %.2e max %.2e" %
+                  (mode, frac_same, d.max(), pts[mode], pts["f32"], dn.max(), np.median(nn), nn.max()))
+            assert frac_same > (0.9999 if mode == "bf16x6" else 0.999), mode
+            assert abs(int(pts[mode]) - int(pts["f32"])) <= 0.002 * pts["f32"] and dn.max() < 0.01, mode
+            # (areas that differ in their last bits move a few draws onto the neighbouring triangle of the cumulative-area search - or, for a
+            # changed soup, anywhere on the surface: those samples are a sample spacing away from the f32 run's, not on top of one)
+            assert np.median(nn) < 1e-3 and np.quantile(nn, 0.9 if mode == "bf16x3" else 0.99) < 2e-2 and nn.max() < 0.15, mode
+    finally:
+        r.close()
