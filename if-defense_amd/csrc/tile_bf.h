@@ -301,6 +301,14 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     // occasionally delivers a wrong result on gfx950 (scripts/pk_mfma_coexec.hip, profiles/r05_pk_mfma_coexec.txt: 0 wrong of 5e9
     // beside an idle or an f32-MFMA partner, 16 ... 300 of 5e9 beside a bf16-MFMA partner - ~1 % of a launch's sub-tiles here).
     // decoder_tile3's packed sampling is therefore spelled out value by value: same operations, same order, same roundings.
+    // The sampling Jacobian (IFD_BF_JAC, default on): d c[ch] / d pix along the plane's two axes, summed over the planes that share an
+    // axis - 3 x 8 values per lane and sub-tile, parked in scratch across the MLP - replaces the backward pass's re-gather of the taps
+    // (48 KB of 128-byte lines per tile and wave, the kernel's largest HBM stream: profiles/r05_ab_bf_gather.txt) by 12 KB of
+    // coalesced scratch stores and loads.  J[t][a][ch]: axis 0 <- planes 0, 1; axis 1 <- planes 1, 2; axis 2 <- planes 0, 2.
+#ifndef IFD_BF_JAC
+#define IFD_BF_JAC 1
+#endif
+    [[maybe_unused]] float J[2][3][8];
     auto sample_fwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
 #pragma unroll
@@ -317,6 +325,15 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
                     s1 = __builtin_fmaf(tap[t][2][mt][j], wsw, s1);
                     s1 = __builtin_fmaf(tap[t][3][mt][j], wse, s1);
                     c[t][4 * mt + j] = P == 0 ? s1 : c[t][4 * mt + j] + s1;
+                    if (IFD_BF_JAC && MODE == MODE_OPT) {
+                        const float nw = tap[t][0][mt][j], ne = tap[t][1][mt][j], sw = tap[t][2][mt][j], se = tap[t][3][mt][j];
+                        const float jx = __builtin_fmaf(se - sw, g.w1[a1], (ne - nw) * g.w0[a1]);       // along a0
+                        const float jy = __builtin_fmaf(se - ne, g.w1[a0], (sw - nw) * g.w0[a0]);       // along a1
+                        const int ch = 4 * mt + j;
+                        // first contributions: axis 0 and axis 2 from plane 0, axis 1 from plane 1
+                        J[t][a0][ch] = (P == 0 || (P == 1 && a0 == 1)) ? jx : J[t][a0][ch] + jx;
+                        J[t][a1][ch] = (P == 0 || (P == 1 && a1 == 1)) ? jy : J[t][a1][ch] + jy;
+                    }
                 }
         }
     };
@@ -346,6 +363,18 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         sample_fwd(2, tap2);
         __builtin_amdgcn_sched_barrier(0);
         T2(3);
+    }
+    // park the Jacobian (12 x 16 bytes per lane; a 256-byte private array indexed through an opaque zero: knn_device.h "Parking")
+    [[maybe_unused]] f32x4 jpark[16];
+    if (IFD_BF_JAC && MODE == MODE_OPT) {
+        const int z = opaque_zero();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    jpark[z + (t * 3 + a) * 2 + h] = f32x4{J[t][a][4 * h], J[t][a][4 * h + 1], J[t][a][4 * h + 2], J[t][a][4 * h + 3]};
     }
 
     const SelMat sel = make_selmat(lane);
@@ -502,6 +531,24 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
                 g[t][0] = fmaf(wp.x, d, g[t][0]); g[t][1] = fmaf(wp.y, d, g[t][1]); g[t][2] = fmaf(wp.z, d, g[t][2]);
             }
         }
+    if (IFD_BF_JAC && MODE == MODE_OPT) {
+        // d c / d u from the parked Jacobian: g[a] += lk[a] * sum_ch J[a][ch] dc[ch]  (even / odd channel partial sums)
+        const f32x8 dcj[2] = {flat(dcc[0]), flat(dcc[1])};
+        const int z = opaque_zero();
+        T2(66);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const f32x4 j0 = jpark[z + (t * 3 + a) * 2], j1 = jpark[z + (t * 3 + a) * 2 + 1];
+                float pe = j0[0] * dcj[t][0], po = j0[1] * dcj[t][1];
+                pe = __builtin_fmaf(j0[2], dcj[t][2], pe); po = __builtin_fmaf(j0[3], dcj[t][3], po);
+                pe = __builtin_fmaf(j1[0], dcj[t][4], pe); po = __builtin_fmaf(j1[1], dcj[t][5], po);
+                pe = __builtin_fmaf(j1[2], dcj[t][6], pe); po = __builtin_fmaf(j1[3], dcj[t][7], po);
+                g[t][a] = fmaf(geo[t].lk[a], pe + po, g[t][a]);
+            }
+        T2(69);
+    } else {
     f32x8 dcf[2] = {flat(dcc[0]), flat(dcc[1])};
     auto sample_bwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
         const int a0 = AX0[P], a1 = AX1[P];
@@ -557,6 +604,7 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
         sample_bwd(2, tap2);
         __builtin_amdgcn_sched_barrier(0);
         T2(69);
+    }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
