@@ -301,12 +301,15 @@ __device__ __forceinline__ void decoder_tile3_bf(const float* __restrict__ Wg, _
     // occasionally delivers a wrong result on gfx950 (scripts/pk_mfma_coexec.hip, profiles/r05_pk_mfma_coexec.txt: 0 wrong of 5e9
     // beside an idle or an f32-MFMA partner, 16 ... 300 of 5e9 beside a bf16-MFMA partner - ~1 % of a launch's sub-tiles here).
     // decoder_tile3's packed sampling is therefore spelled out value by value: same operations, same order, same roundings.
-    // The sampling Jacobian (IFD_BF_JAC, default on): d c[ch] / d pix along the plane's two axes, summed over the planes that share an
+    // The sampling Jacobian (IFD_BF_JAC; default: bf16x3 only): d c[ch] / d pix along the plane's two axes, summed over the planes that share an
     // axis - 3 x 8 values per lane and sub-tile, parked in scratch across the MLP - replaces the backward pass's re-gather of the taps
     // (48 KB of 128-byte lines per tile and wave, the kernel's largest HBM stream: profiles/r05_ab_bf_gather.txt) by 12 KB of
     // coalesced scratch stores and loads.  J[t][a][ch]: axis 0 <- planes 0, 1; axis 1 <- planes 1, 2; axis 2 <- planes 0, 2.
+    // Measured on the bench workload (profiles/r05_ab_bf_jacobian.txt): bf16x3 4068 -> 4263 clouds/s (+4.8 %, -11 % cycles per step);
+    // bf16x6 3531 -> 3458 (-2 %: 2 % fewer cycles, but the ~200 extra vector instructions per tile pull the clock from 2.14 to 2.06
+    // GHz - that kernel sits at the socket's power limit, profiles/r05_power_clock.txt).  So: on for bf16x3, off for bf16x6.
 #ifndef IFD_BF_JAC
-#define IFD_BF_JAC 1
+#define IFD_BF_JAC (PREC == 2)
 #endif
     [[maybe_unused]] float J[2][3][8];
     auto sample_fwd = [&](int P, const f32x4 (&tap)[2][4][2]) {
