@@ -607,15 +607,25 @@ def main():
         achieved = flop_per_cloud * avg_clouds / (avg_ms * 1e-3) / 1e12
         # HBM bytes per launch from the PMC passes (scripts/collect_profiles.sh; counters cannot be read inside this run):
         # quoted only if they were measured on THIS kernel (source hash) and this launch size, else null
+        # a file is one launch, or two (pipeline.defend_stream tail_first: the partial round, then the whole rounds); `achieved` is
+        # over ALL launches of the kernel (what rocprofv3's per-kernel average corresponds to), the shapes are listed next to it
+        launches_per_file = len(kern_ms) / float(a.steps)
+        shapes = {}
+        for ms_, n_ in zip(kern_ms, kern_clouds):
+            shapes.setdefault(n_, []).append(ms_)
+        launch_shapes = [{"clouds": n_, "ms": round(sum(v) / len(v), 2),
+                          "frac": round(flop_per_cloud * n_ / (sum(v) / len(v) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+                         for n_, v in sorted(shapes.items(), reverse=True)]
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tf) and not onet and avg_clouds == N_CLOUDS:
+        if os.path.exists(tf) and not onet and abs(sum(kern_clouds) / float(a.steps) - N_CLOUDS) < 0.5:
             tj = json.load(open(tf))
-            if tj.get("kernel_source_sha") == kernel_source_sha():
+            if tj.get("kernel_source_sha") == kernel_source_sha() and tj.get("launches_per_file", 1) == launches_per_file:
                 traffic = tj.get("optimize_kernel_hbm_bytes_per_launch")
-                traffic_src = "profiles/roofline_traffic.json (rocprofv3 PMC passes of this kernel, fetch factor %.2f)" % tj.get("fetch_factor", 2.0)
+                traffic_src = "profiles/roofline_traffic.json (rocprofv3 PMC passes of this kernel, fetch factor %.2f; %g launch(es) per file, " \
+                              "bytes per average launch)" % (tj.get("fetch_factor", 2.0), launches_per_file)
             else:
-                traffic_src = "profiles/roofline_traffic.json is from another build of the kernel - not quoted"
+                traffic_src = "profiles/roofline_traffic.json is from another build of the kernel or another launch scheme - not quoted"
         res = {
             "metric": "restored clouds/sec (1024-pt ModelNet40, %s 500 iters)" % ("ONet-Opt" if onet else "ConvONet-Opt"),
             "value": round(total * a.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": a.steps,
@@ -627,7 +637,8 @@ def main():
                        "clouds_per_gpu": per, "clouds_total": total, "points": K_POINTS, "adam_steps": ITERATIONS + 1,
                        "parallelism": "shard%d+allgather" % world, "weights": "seeded random (seed 0)",
                        "driver": "stream of %d files: pre-processing of file n+1 on a second HIP stream under file n's optimiser tail" % a.steps
-                                 if not a.no_overlap else "one file at a time, device synchronisation after every file (BASELINE configs[1] literally)",
+                                 if not a.no_overlap else "one file at a time, device synchronisation after every file (BASELINE configs[1] literally); inside a file the clouds of its "
+                                 "partial last round go first and the other clouds' pre-processing runs under that round (pipeline.defend_stream tail_first)",
                        "arith": "f32 throughout; decoder layers on v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain); repulsion terms' "
                                 "sqrt / 1/h / 1/d / exp through the 1-ulp hardware instructions (IFD_EXACT_REP off; libifd_exact.so has the "
                                 "IEEE expansions, +1.3 %); ReLU'(+0.0) passes in the hot tile (DESIGN section 10)"},
@@ -635,7 +646,8 @@ def main():
                          "achieved": round(achieved, 2),
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(avg_ms, 2),
-                         "clouds_per_launch": avg_clouds, "flop_per_cloud": flop_per_cloud},
+                         "clouds_per_launch": avg_clouds, "flop_per_cloud": flop_per_cloud,
+                         "launches_per_file": launches_per_file, "launch_shapes": launch_shapes},
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
             "gather_ms": round(sum(g0.elapsed_time(g1) for g0, g1 in gev) / max(1, len(gev)), 3),
         }

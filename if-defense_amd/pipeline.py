@@ -52,7 +52,7 @@ def _prepare_unit(r: Restorer, xb: torch.Tensor, args: DefenseArgs, base: int, t
     return prep["init"], planes, lb
 
 
-def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=None, overlap: bool = True):
+def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=None, overlap: bool = True, tail_first: bool = True):
     """Restore a SEQUENCE of arrays (the files of a --data_root directory, the steps of a benchmark), yielding one
     restored device tensor [N_i, sample_npoint, 3] per array, in order.
 
@@ -62,6 +62,12 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
     the tail frees instead of after it.  Results are bit-identical to the serial order: every kernel is deterministic and
     the passes share nothing but read-only weights (the context's encoder scratch is used by one pass at a time: the
     side stream's work is ordered, and the optimiser uses the separate neighbour-list scratch).
+
+    ``tail_first`` (round 5) does the same INSIDE a file: the clouds of its partial last round (n mod CUs) are prepared and
+    optimised first - their round occupies that many CUs - and the pre-processing of the file's other clouds runs on the second
+    stream on the CUs that round leaves idle; then the whole rounds follow.  Same kernels on the same clouds (random draws and the
+    1 / B factor are keyed by the global cloud index): bit-identical output, and no work of another file is involved, so a single
+    file (``overlap=False``: BASELINE configs[1]) benefits too.
 
     Lazy: ``arrays`` may be a generator (the CLI loads the files of a directory on demand).  Array i + 1 is pulled,
     uploaded and given its output tensor only when its first device pass is about to be prepared - one pass ahead of the
@@ -73,6 +79,7 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
     on_gpu = torch.device(r.device).type == "cuda"           # (the host tests drive this with a stand-in model on the CPU)
     main = torch.cuda.current_stream(r.device) if on_gpu else None
     side = None
+    n_cu = torch.cuda.get_device_properties(r.device).multi_processor_count if on_gpu else 0
 
     def units():
         """(array index, holder of the array's input / output tensors, lo, hi, last pass of its array), one device pass each"""
@@ -84,6 +91,11 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
                 # the side stream waits for exactly that (an event recorded now), not for the optimiser launches that follow
                 h["ev_in"] = torch.cuda.Event()
                 h["ev_in"].record(main)
+            rest = n % n_cu if n_cu else 0
+            if tail_first and rest and n > n_cu and n <= int(args.chunk) and int(args.sample_npoint) <= 1024:
+                yield i, h, n - rest, n, False                       # the partial round first ...
+                yield i, h, 0, n - rest, True                        # ... the whole rounds behind it
+                continue
             los = list(range(0, max(n, 1), int(args.chunk)))
             for lo in los:
                 yield i, h, lo, min(n, lo + int(args.chunk)), lo == los[-1]
@@ -98,13 +110,20 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
             h["pc"] = None
         return h["x"]
 
-    def launch_prepare(u):
+    def launch_prepare(u, after=None):
+        """``after``: the unit whose optimiser launch has just been enqueued.  All pre-processing runs on the side stream (one
+        stream: the passes' uses of the context's encoder scratch stay ordered); without ``overlap`` another FILE's pre-processing
+        first waits for everything on the main stream - it does not run under the previous file's optimiser, only a unit of the
+        same file does (tail_first)."""
         i, h, lo, hi, last = u
+        use_side = side is not None
+        if use_side and not overlap and after is not None and after[0] != i:
+            side.wait_stream(main)
         base = 0 if bases is None else bases[i]
         total = int(totals[i] if (totals is not None and totals[i] is not None) else base + h["out"].shape[0])
         if hi <= lo:
             return None
-        if side is None:
+        if not use_side:
             res = _prepare_unit(r, upload(h)[lo:hi], args, base + lo, total) + (None,)
         else:
             with torch.cuda.stream(side):         # (side-stream order keeps the passes' use of the encoder scratch apart)
@@ -123,7 +142,7 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
     if cur_u is None:
         return
     nxt_u = next(it, None)
-    if on_gpu and overlap and nxt_u is not None:
+    if on_gpu and (overlap or tail_first) and nxt_u is not None:
         side = torch.cuda.Stream(r.device)
         side.wait_stream(main)                    # inputs already on the device were produced on the main stream
     ready = launch_prepare(cur_u)
@@ -137,7 +156,7 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
                                                 lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing,
                                                 **({"check": False} if on_gpu and hasattr(r, "check_status") else {}),
                                                 **({"precision": args.precision} if getattr(args, "precision", "f32") != "f32" else {}))
-        ready = launch_prepare(nxt_u) if nxt_u is not None else None               # rides on the optimiser's tail
+        ready = launch_prepare(nxt_u, cur_u) if nxt_u is not None else None        # rides on the optimiser's tail
         if last:
             if on_gpu and hasattr(r, "check_status") and os.environ.get("IFD_STATUS_CHECK", "1") != "0":
                 # device-side failures of this file's launches (a split cloud's wait that gave up, fixed-point sums near

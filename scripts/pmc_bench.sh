@@ -24,11 +24,14 @@ for f in glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True):
     if not rows:
         continue
     big = max(int(r["Grid_Size"]) for r in rows)
+    wg = next(int(r.get("Workgroup_Size", 512) or 512) for r in rows if int(r["Grid_Size"]) == big)
+    clouds = big // wg                       # the largest launch of the file (with the partial round first: its whole rounds), one workgroup of 512 threads per cloud
     disp = sorted({r["Dispatch_Id"] for r in rows if int(r["Grid_Size"]) == big})[-1]
     for r in rows:
         if r["Dispatch_Id"] == disp:
             acc[r["Counter_Name"]] += float(r["Counter_Value"])
 a = dict(acc)
+a["clouds_in_the_measured_launch"] = clouds
 waves = clouds * 8
 if a.get("SQ_WAVE_CYCLES"):
     # SQ_WAVE_CYCLES counts in units of 4 cycles; two waves share a SIMD, so SIMD-resident cycles = wave cycles / 2
@@ -44,7 +47,7 @@ if a.get("SQ_WAVE_CYCLES"):
     a["valu_issue_frac_at_4_cycles"] = 4.0 * nv / simd
     a["pipe_occupancy_lower_bound"] = (a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) + 4.0 * nv) / simd
     a["lds_issue_frac"] = a.get("SQ_ACTIVE_INST_LDS", 0) * 4 / simd if a.get("SQ_ACTIVE_INST_LDS") else None
-a["command"] = "bash scripts/pmc_bench.sh $TAG $CLOUDS: separate rocprofv3 --pmc passes over bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline --no-overlap (one optimize_kernel launch of $CLOUDS clouds x 501 steps on the bench workload)"
+a["command"] = "bash scripts/pmc_bench.sh $TAG $CLOUDS: separate rocprofv3 --pmc passes over bench.py --steps 1 --warmup 0 --clouds $CLOUDS --no-extras --no-cpu-baseline --no-overlap (the largest optimize_kernel launch of the $CLOUDS-cloud file x 501 steps on the bench workload)"
 json.dump(a, open("$R/gpurun_out/pmc_bench_$TAG.json", "w"), indent=1)
 print(json.dumps(a, indent=1))
 PY

@@ -26,13 +26,19 @@ if f:
             res["optimize_kernel_share_pct"] = float(r["Percentage"])
 
 
+n_dispatch = {}
+
+
 def pmc(sub):
     f = find(sub, "*counter_collection.csv")
     acc = {}
     if f:
+        ids = set()
         for r in csv.DictReader(open(f)):
             if "optimize_kernel" in r["Kernel_Name"] and "onet" not in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                ids.add(r["Dispatch_Id"])
+        n_dispatch[sub] = len(ids)
         keep = [r for r in csv.DictReader(open(f)) if "optimize_kernel" in r["Kernel_Name"] and "onet" not in r["Kernel_Name"]]
         if keep:
             with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, sub)), "w", newline="") as o:
@@ -73,19 +79,23 @@ def calibration():
 fetch, write, tcc = pmc("fetch"), pmc("write"), pmc("tcc")
 factor, calib = calibration()
 if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
-    rd = factor * fetch["FETCH_SIZE"] * 1024.0   # gfx950: FETCH_SIZE under-reports; factor calibrated on the tile's own pattern
-    wr = write["WRITE_SIZE"] * 1024.0
+    # the passes run ONE file (bench.py --steps 1 --warmup 0): its optimiser launches (one, or two with the partial round first) are
+    # summed, the figures are per AVERAGE launch like bench.py's roofline.achieved
+    launches = max(1, n_dispatch.get("fetch", 1))
+    rd = factor * fetch["FETCH_SIZE"] * 1024.0 / launches   # gfx950: FETCH_SIZE under-reports; factor calibrated on the tile's own pattern
+    wr = write["WRITE_SIZE"] * 1024.0 / launches
     res.update({
         "command": "scripts/collect_profiles.sh %s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum, "
                    "separate passes over python bench.py --steps 1 --warmup 0 --no-cpu-baseline)" % tag,
-        "kernel": "ifd::optimize_kernel, one launch = 2468 clouds x 1024 points x 501 Adam steps",
+        "kernel": "ifd::optimize_kernel; one file = 2468 clouds x 1024 points x 501 Adam steps in launches_per_file launches",
+        "launches_per_file": float(launches),
         "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
         "correction": "read bytes = fetch_factor * FETCH_SIZE * 1024 with fetch_factor calibrated by scripts/gather_calib "
                       "(a known byte count in the tile's gather pattern; MI355X_MICROARCH.md, HBM section: 2.0 for wide "
                       "streaming reads); WRITE_SIZE taken at face value",
         "fetch_factor": factor, "fetch_calibration": calib, "kernel_source_sha": source_sha(),
         "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-        "optimize_kernel_hbm_bytes_per_launch": rd + wr, "per_cloud_bytes": (rd + wr) / 2468.0,
+        "optimize_kernel_hbm_bytes_per_launch": rd + wr, "per_cloud_bytes": (rd + wr) * launches / 2468.0,
         "algorithmic_gather_bytes_per_cloud": 788004864,
     })
     if "TCC_HIT_sum" in tcc:

@@ -1684,6 +1684,26 @@ def test_streamed_driver_equals_serial_passes(restorer, golden):
             assert torch.equal(s_, t_)
 
 
+def test_partial_round_first_is_bit_identical(restorer):
+    """pipeline.defend_stream(tail_first=True) (round 5): the clouds of a file's partial last round (n mod CUs) prepared and optimised
+    first, the pre-processing of the others on the second stream under that round - same output, bit for bit, as the one-pass order;
+    one file and a stream of two, with and without cross-file overlap."""
+    import bench
+    import ifdefense_amd as I
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    a = bench.synth_clouds(n_cu + 44, seed=60)
+    b = bench.synth_clouds(2 * n_cu + 3, seed=61)
+    args = I.DefenseArgs(iterations=6, batch_size=192, seed=3)
+    ref = [o.clone() for o in I.defend_stream(restorer, [a, b], args, bases=[0, 1000], totals=[len(a), 1000 + len(b)],
+                                             overlap=False, tail_first=False)]
+    for overlap in (False, True):
+        got = [o.clone() for o in I.defend_stream(restorer, [a, b], args, bases=[0, 1000], totals=[len(a), 1000 + len(b)],
+                                                 overlap=overlap, tail_first=True)]
+        assert len(got) == 2 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), overlap
+    one = I.defend_point_cloud(restorer, a, args, cloud_index_base=0, total_clouds=len(a), return_device=True)
+    assert torch.equal(one, ref[0])
+
+
 def test_lists_equal_scan_on_mixed_inputs(restorer):
     """Regression net for the neighbour lists (exact ties, refreshes, ragged K): a slice of scripts/fuzz_lists_vs_scan.py."""
     import bench
