@@ -277,7 +277,7 @@ def split_precision_extras(r, x, args, lo, total, ev):
             for _ in I.defend_stream(r, [x] * 2, args, bases=[lo] * 2, totals=[total] * 2, overlap=False):
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 2
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) / max(1, len(ev))
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) / 2.0           # per FILE: the sum of its launches (partial round + whole rounds)
             out[mode] = {"value": round(total / dt, 1), "unit": "clouds/s", "ms_per_file": round(dt * 1e3, 1), "optimiser_launch_ms": round(ms, 1),
                          "f32_equivalent_tflops": round(FLOP_DENSE_PER_CLOUD * total / (ms * 1e-3) / 1e12, 1),
                          "precision": "f32-equivalent (three exact bf16 pieces per operand, six products, f32 accumulation)" if mode == "bf16x6"
@@ -287,7 +287,8 @@ def split_precision_extras(r, x, args, lo, total, ev):
         finally:
             os.environ.pop("IFD_PRECISION", None)
     out["what"] = ("opt-in arithmetic of the decoder's 32 x 32 layers, never the headline: one 2468-cloud file at a time, mean of 2; "
-                   "f32_equivalent_tflops = algorithmic decoder FLOPs / optimiser launch time (the f32-MFMA peak is 157.3)")
+                   "optimiser_launch_ms = the file's optimiser launches together; f32_equivalent_tflops = algorithmic decoder FLOPs / that time "
+                   "(the f32-MFMA peak is 157.3)")
     return out
 
 
