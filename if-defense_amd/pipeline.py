@@ -201,7 +201,8 @@ def remesh_point_cloud(r, pc, args: "DefenseArgs", cloud_index_base: int = 0, re
         prep = r.prepare(xb, keep, n_sel=args.input_npoint, n_opt=n, padding_scale=args.padding_scale,
                          init_sigma=args.init_sigma, seed=args.seed, cloud_index_base=cloud_index_base + lo)
         c = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
-        res = r.mesh_sample(c, n_sample=n, seed=args.seed, cloud_index_base=cloud_index_base + lo)
+        res = r.mesh_sample(c, n_sample=n, seed=args.seed, cloud_index_base=cloud_index_base + lo,
+                            **({"precision": args.precision} if getattr(args, "precision", "f32") != "f32" else {}))
         pts = res["points"]
         empty = (res["n_triangles"] == 0).nonzero().flatten().tolist()
         for b in empty:                                          # rare: reconstruction failed

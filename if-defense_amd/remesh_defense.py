@@ -32,6 +32,9 @@ def build_parser():
     parser.add_argument('--sor_alpha', type=float, default=1.1, help='Threshold = mean + alpha * std')
     parser.add_argument('--seed', type=int, default=0, help='seed of the counter-based random draws')
     parser.add_argument('--weights', type=str, default='', help='checkpoint (.pth); default: cfg test.model_file')
+    parser.add_argument('--precision', choices=('f32', 'bf16x6', 'bf16x3'), default='f32',
+                        help="arithmetic of the decoder layers in the MISE grid evaluation (opt-in extension, ifd_mesh_params.precision; "
+                             "default f32: the grid is bit-identical to the reference's MISE class on the same decoder values)")
     return parser
 
 
@@ -57,7 +60,7 @@ def main(argv=None):
     r = OnetRestorer(weights.load_checkpoint(args.weights or cfg['test']['model_file'], "onet"),
                      device=torch.device('cuda', local), threshold=cfg['test']['threshold'])
     dargs = DefenseArgs(sample_npoint=args.sample_npoint, padding_scale=args.padding_scale, sor=args.sor, sor_k=args.sor_k,
-                        sor_alpha=args.sor_alpha, threshold=cfg['test']['threshold'], input_npoint=cfg['data']['pointcloud_n'],
+                        sor_alpha=args.sor_alpha, threshold=cfg['test']['threshold'], input_npoint=cfg['data']['pointcloud_n'], precision=args.precision,
                         seed=args.seed)
 
     def defend(pc, normalize=True):
