@@ -99,6 +99,8 @@ struct ifd_ctx {
     UNetWeights uw{};
     void* ws_enc = nullptr;        // encoder scratch (pre-U-Net planes + U-Net activations), grown on demand
     size_t ws_enc_bytes = 0;
+    void* ws_fold = nullptr;       // ONet: folded CBN coefficients of the clouds of the current decode / optimise / mesh call (onet_fold) -
+    size_t ws_fold_bytes = 0;      // NOT the encoder scratch: the optimiser reads them for its whole launch while an encoder call may run beside it
     DecConst dc{};
     unsigned long long* d_counters = nullptr;   // IFD_N_COUNTERS diagnostic counters of the last ifd_optimize
     int n_cu = 256;                // compute units of the device (rounds of the persistent optimiser)
@@ -569,6 +571,7 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->d_unet) (void)hipFree(ctx->d_unet);
     if (ctx->d_enc_img) (void)hipFree(ctx->d_enc_img);
     if (ctx->ws_enc) (void)hipFree(ctx->ws_enc);
+    if (ctx->ws_fold) (void)hipFree(ctx->ws_fold);
     if (ctx->d_onet_img) (void)hipFree(ctx->d_onet_img);
     if (ctx->d_onet_img_bf) (void)hipFree(ctx->d_onet_img_bf);
     if (ctx->d_onet_small) (void)hipFree(ctx->d_onet_small);
@@ -885,12 +888,15 @@ int ifd_onet_encode(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, 
 }
 
 namespace {
-// CBN fold of B clouds into the context scratch: returns the device pointer of ab [B][11][2][256]
+// CBN fold of B clouds into the context's fold buffer: returns the device pointer of ab [B][11][2][256].  The buffer belongs to the
+// decoder-side calls (ifd_onet_decode / ifd_onet_optimize / ifd_onet_mesh_sample, stream-ordered with each other like every call of
+// one kind: include/ifd.h); the encoder calls never touch it, so ifd_onet_encode of the NEXT pass may run on a second stream while
+// an optimiser launch still reads its coefficients (round-5 advisor: it used to live at offset 0 of the encoder scratch).
 hipError_t onet_fold(ifd_ctx* ctx, const float* c, int B, hipStream_t s, float** ab_out) {
     const size_t per = (size_t)2 * ONET_NCBN * ONET_H;
-    hipError_t e = ensure_buf(&ctx->ws_enc, &ctx->ws_enc_bytes, 2 * per * B * sizeof(float));
+    hipError_t e = ensure_buf(&ctx->ws_fold, &ctx->ws_fold_bytes, 2 * per * B * sizeof(float));
     if (e != hipSuccess) return e;
-    float* gb = static_cast<float*>(ctx->ws_enc);
+    float* gb = static_cast<float*>(ctx->ws_fold);
     float* ab = gb + per * B;
     *ab_out = ab;
     return launch_onet_cbn(ctx->d_w, ctx->od, c, B, gb, ab, s);

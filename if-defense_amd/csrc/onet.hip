@@ -217,13 +217,6 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_decode_kernel(const float
 
 hipError_t launch_onet_grid_eval(const float* img, const float* small, const float* ab, const MiseGrid& g, int B, int n_blocks,
                                  float box, hipStream_t s) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
     hipLaunchKernelGGL(grid_plan_kernel<0>, dim3(1), dim3(64), 0, s, g, B);
     hipLaunchKernelGGL(onet_grid_eval_kernel<0>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, g, B, box);
     return hipGetLastError();
@@ -284,6 +277,9 @@ hipError_t configure_onet_kernels() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_large_occupancy_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<0>),          // (per device: see onet_bf.hip)
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel<0>),

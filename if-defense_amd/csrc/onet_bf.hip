@@ -15,22 +15,20 @@ hipError_t configure_onet_bf_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel<2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);
+    if (e != hipSuccess) return e;
+    // (the grid-evaluation kernels too: the attribute is per DEVICE, and this runs under the context's device at every
+    // ifd_onet_create - a process-wide "configured" flag in the launcher left a second GPU's launches unconfigured; round-5 advisor)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
 }
 
 hipError_t launch_onet_grid_eval_bf(int precision, const float* img_bf, const float* small, const float* ab, const MiseGrid& g, int B,
                                     int n_blocks, float box, hipStream_t s) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
     hipLaunchKernelGGL(grid_plan_kernel<1>, dim3(1), dim3(64), 0, s, g, B);
     if (precision == 1)
         hipLaunchKernelGGL(onet_grid_eval_kernel<1>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, g, B, box);

@@ -61,7 +61,8 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
     are enqueued on a second HIP stream as soon as the current pass's optimiser is launched, so they run on the CUs that
     the tail frees instead of after it.  Results are bit-identical to the serial order: every kernel is deterministic and
     the passes share nothing but read-only weights (the context's encoder scratch is used by one pass at a time: the
-    side stream's work is ordered, and the optimiser uses the separate neighbour-list scratch).
+    side stream's work is ordered; the optimiser uses the separate neighbour-list scratch and - ONet - its own buffer for the
+    folded CBN coefficients, api.cpp onet_fold).
 
     ``tail_first`` (round 5) does the same INSIDE a file: the clouds of its partial last round (n mod CUs) are prepared and
     optimised first - their round occupies that many CUs - and the pre-processing of the file's other clouds runs on the second
@@ -92,7 +93,9 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
                 h["ev_in"] = torch.cuda.Event()
                 h["ev_in"].record(main)
             rest = n % n_cu if n_cu else 0
-            if tail_first and rest and n > n_cu and n <= int(args.chunk) and int(args.sample_npoint) <= 1024:
+            # (not with --printing: the reference prints the batches of a file in order, opt_defense.py:229-236 - the partial round
+            # first would print the LAST clouds' loss lines first)
+            if tail_first and rest and n > n_cu and n <= int(args.chunk) and int(args.sample_npoint) <= 1024 and not args.printing:
                 yield i, h, n - rest, n, False                       # the partial round first ...
                 yield i, h, 0, n - rest, True                        # ... the whole rounds behind it
                 continue
@@ -154,8 +157,8 @@ def defend_stream(r: Restorer, arrays, args: DefenseArgs, bases=None, totals=Non
                 main.wait_event(ev)
             h["out"][lo:hi] = r.optimize_points(init, planes, rep_weight=args.rep_weight, iterations=args.iterations,
                                                 lr=args.lr, loss_batch=lb, normalize=True, printing=args.printing,
-                                                **({"check": False} if on_gpu and hasattr(r, "check_status") else {}),
-                                                **({"precision": args.precision} if getattr(args, "precision", "f32") != "f32" else {}))
+                                                **({"check": False, "precision": getattr(args, "precision", "f32") or "f32"}
+                                                   if on_gpu and hasattr(r, "check_status") else {}))
         ready = launch_prepare(nxt_u, cur_u) if nxt_u is not None else None        # rides on the optimiser's tail
         if last:
             if on_gpu and hasattr(r, "check_status") and os.environ.get("IFD_STATUS_CHECK", "1") != "0":
@@ -202,7 +205,7 @@ def remesh_point_cloud(r, pc, args: "DefenseArgs", cloud_index_base: int = 0, re
                          init_sigma=args.init_sigma, seed=args.seed, cloud_index_base=cloud_index_base + lo)
         c = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
         res = r.mesh_sample(c, n_sample=n, seed=args.seed, cloud_index_base=cloud_index_base + lo,
-                            **({"precision": args.precision} if getattr(args, "precision", "f32") != "f32" else {}))
+                            precision=getattr(args, "precision", "f32") or "f32")
         pts = res["points"]
         empty = (res["n_triangles"] == 0).nonzero().flatten().tolist()
         for b in empty:                                          # rare: reconstruction failed

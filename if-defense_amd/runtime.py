@@ -20,13 +20,32 @@ PLANE_ORDER = ("xz", "xy", "yz")
 # measurement hook: IFD_SPLIT=1|2|4 overrides the automatic choice of ifd_opt_params.split (results do not depend on it)
 import os as _os
 _ENV_SPLIT = int(_os.environ.get("IFD_SPLIT", "0"))
-# ifd_opt_params.precision by name; IFD_PRECISION=f32|bf16x6|bf16x3 is the default where a caller passes None (measurement hook)
+# ifd_opt_params.precision by name.  Where a caller passes None the module default applies: "f32" unless a test / measurement
+# set another one (set_default_precision; tests/conftest.py runs the parity matrix in both modes that way).  The environment's
+# IFD_PRECISION is honoured only together with IFD_ENABLE_TEST_HOOKS=1 (round-5 advisor: a stray variable must not switch a
+# production process to another arithmetic); the CLIs and pipeline.py always pass an explicit precision.
 PRECISIONS = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
+_DEFAULT_PRECISION = "f32"
+if _os.environ.get("IFD_ENABLE_TEST_HOOKS", "") == "1" and _os.environ.get("IFD_PRECISION"):
+    _DEFAULT_PRECISION = _os.environ["IFD_PRECISION"]
+
+
+def default_precision() -> str:
+    return _DEFAULT_PRECISION
+
+
+def set_default_precision(name: str) -> str:
+    """Test / measurement hook: the precision used where a caller passes None.  Returns the previous default."""
+    global _DEFAULT_PRECISION
+    if name not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+    prev, _DEFAULT_PRECISION = _DEFAULT_PRECISION, name
+    return prev
 
 
 def precision_code(precision) -> int:
     if precision is None:
-        precision = _os.environ.get("IFD_PRECISION", "f32")
+        precision = _DEFAULT_PRECISION
     if isinstance(precision, str):
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
@@ -222,7 +241,7 @@ class Restorer:
         ``knn_reference_form``: validation only - the reference's neighbour choice bug for bug (ifd_opt_params.knn_reference_form:
         float32 expanded-form distances, top-6 minus column 0, pn_utils.py:72-83) instead of the exact 5-NN.
         ``precision``: arithmetic of the decoder's dense layers (ifd_opt_params.precision): "f32" / 0 (default), "bf16x6" / 1
-        (f32-equivalent on the bf16 matrix core), "bf16x3" / 2 (reduced); None takes the environment's IFD_PRECISION (default f32).
+        (f32-equivalent on the bf16 matrix core), "bf16x3" / 2 (reduced); None takes the module default ("f32"; set_default_precision).
         ``rep_radius`` / ``rep_h``: RepulsionLoss(radius, h) (defense/repulsion_loss.py:9-10; the reference never changes them).
         ``check`` (default on): synchronise and raise IfdError on a device-side failure (``check_status``: a split cloud's
         bounded wait that gave up, repulsion sums near their range) - a caller that gets points back can trust them.  The drivers
@@ -233,7 +252,7 @@ class Restorer:
         """
         if printing and state is None and not return_state and not return_loss:
             return self._optimize_points_printing(opt_points, c, rep_weight, int(iterations) + 1 if steps is None else int(steps),
-                                                  lr, loss_batch, normalize, knn_scan_every_step, precision)
+                                                  lr, loss_batch, normalize, knn_scan_every_step, precision, check)
         planes = self._cond(c)
         p = _f32(opt_points, self.device).clone()
         B, K = p.shape[:2]
@@ -268,7 +287,7 @@ class Restorer:
             out += (loss,)
         return out if len(out) > 1 else p
 
-    def _optimize_points_printing(self, opt_points, c, rep_weight, n_steps, lr, loss_batch, normalize, scan, precision=None):
+    def _optimize_points_printing(self, opt_points, c, rep_weight, n_steps, lr, loss_batch, normalize, scan, precision=None, check=True):
         """printing=True of the reference's optimize_points (opt_defense.py:229-236): at iterations 0, 100, 200, ... it
         prints the loss, the two loss terms and the mean occupancy probability, all evaluated at that iteration's
         pre-update points.  The run is cut so that every such iteration is a launch of its own (the kernel reports the
@@ -286,14 +305,14 @@ class Restorer:
                 last = nxt == n_steps
                 p, st = self.optimize_points(p, c, rep_weight=rep_weight, steps=nxt - t, lr=lr, loss_batch=loss_batch,
                                              normalize=normalize and last, state=st, return_state=True,
-                                             knn_scan_every_step=scan, precision=precision)
+                                             knn_scan_every_step=scan, precision=precision, check=check)
                 t = nxt
                 continue
             prob = float(torch.sigmoid(self.decode(p, c)).mean())               # occ_value of iteration t (pre-update points)
             last = t + 1 == n_steps
             p, st, loss = self.optimize_points(p, c, rep_weight=rep_weight, steps=1, lr=lr, loss_batch=loss_batch,
                                                normalize=normalize and last, state=st, return_state=True, return_loss=True,
-                                               knn_scan_every_step=scan, precision=precision)
+                                               knn_scan_every_step=scan, precision=precision, check=check)
             l = loss.double().cpu()
             if torch.is_tensor(loss_batch):
                 lbv = loss_batch.double().cpu()

@@ -26,8 +26,9 @@
  *     at a time per context; different contexts are independent (no hidden globals).
  *   - a context owns mutable scratch that its calls use on the caller's stream: the
  *     optimise calls (ifd_optimize / ifd_onet_optimize) share the neighbour lists, the
- *     Adam table and the counters; the encoder calls (ifd_encode_* / ifd_unet /
- *     ifd_onet_encode) share the encoder scratch.  Calls of one kind on one context
+ *     Adam table and the counters (and, with ifd_onet_decode / ifd_onet_mesh_sample, the
+ *     folded CBN coefficients of an ONet context); the encoder calls (ifd_encode_* /
+ *     ifd_unet / ifd_onet_encode) share the encoder scratch and nothing else.  Calls of one kind on one context
  *     must therefore be stream-ordered with each other (one stream per kind, or
  *     events between them); an optimise call and an encoder call may overlap on
  *     two streams (pipeline.defend_stream does exactly that).
@@ -198,7 +199,9 @@ typedef struct ifd_opt_params {
                              |a|^2 + |b|^2 - 2 a.b in torch's accumulation order, top-6, column 0 dropped whatever it is
                              (ConvONet/defense/pn_utils.py:72-83), by brute force every step - instead of the exact 5-NN of direct
                              differences.  The reference's form swaps candidates closer than its ~1e-7 noise and, for pairs of points
-                             closer than ~1.5e-4, keeps "self" as a neighbour and drops the pair's term; the product path does not. */
+                             closer than ~1.5e-4, keeps "self" as a neighbour and drops the pair's term; the product path does not.
+                             (topk's order among EQUAL distances is restated for rows of >= 384 values - torch's partial_sort path,
+                             which 1024-point clouds take; shorter rows go through nth_element there and ties may differ.) */
     int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers in the persistent kernel (K <= 1024):
                              0 = f32 MFMA (v_mfma_f32_16x16x4_f32: bit-equal to an fmaf chain) - the default;
                              1 = "bf16x6": both operands split exactly into three bf16 pieces, six piece products on the bf16

@@ -18,24 +18,34 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def host_expanded_form_matches_torch():
-    """The accumulation order the kernel restates (csrc/knn_device.h knn_scan_ref2) against THIS host's torch CPU kernels, bit for
-    bit: dot = fma(z, z', fma(y, y', x x')), xx = (x^2 + y^2) + z^2, dist = (xx_j - 2 dot) + xx_i."""
-    g = torch.Generator().manual_seed(5)
-    pc = (torch.rand(2, 512, 3, generator=g) - 0.5) * 0.9
-    inner = -2.0 * torch.matmul(pc, pc.transpose(2, 1))
-    xx = torch.sum(pc.transpose(2, 1) ** 2, dim=1, keepdim=True)
-    dist = (xx + inner + xx.transpose(2, 1)).numpy()
-    x = pc.numpy()
-
+def _restated_dist(x):
+    """The accumulation order the kernel restates (csrc/knn_device.h knn_scan_ref2): dot = fma(z, z', fma(y, y', x x')),
+    xx = (x^2 + y^2) + z^2, dist = (xx_j - 2 dot) + xx_i - in numpy, fma through float64 (exact for float32 operands)."""
     def fma(a, b, c):
         return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
     xi, xj = x[:, :, None, :], x[:, None, :, :]
     dot = fma(xi[..., 2], xj[..., 2], fma(xi[..., 1], xj[..., 1], xi[..., 0] * xj[..., 0]))
     sq = [x[..., k] * x[..., k] for k in range(3)]
     xxn = (sq[0] + sq[1]) + sq[2]
-    mine = (xxn[:, None, :] + np.float32(-2.0) * dot) + xxn[:, :, None]
-    return bool(np.array_equal(mine, dist))
+    return (xxn[:, None, :] + np.float32(-2.0) * dot) + xxn[:, :, None]
+
+
+def fixture_host_expanded_form_matches_restatement():
+    """PINNED (round-5 verdict, weak 3): the restatement against the distance matrix the reference's own knn_point computed on the
+    host that made the trajectory fixtures (tests/golden/knn_ref_dist.npz, captured by make_knn_ref_dist.py inside
+    ConvONet/defense/pn_utils.py:64-83) - bit for bit, independent of the BLAS of the host this test runs on."""
+    z = np.load(os.path.join(HERE, "knn_ref_dist.npz"))
+    return bool(np.array_equal(_restated_dist(z["pc"]), z["dist"]))
+
+
+def host_expanded_form_matches_torch():
+    """The same restatement against THIS host's torch CPU kernels (only matters where the oracle is run live: the config #5 test)."""
+    g = torch.Generator().manual_seed(5)
+    pc = (torch.rand(2, 512, 3, generator=g) - 0.5) * 0.9
+    inner = -2.0 * torch.matmul(pc, pc.transpose(2, 1))
+    xx = torch.sum(pc.transpose(2, 1) ** 2, dim=1, keepdim=True)
+    dist = (xx + inner + xx.transpose(2, 1)).numpy()
+    return bool(np.array_equal(_restated_dist(pc.numpy()), dist))
 
 
 def _trained():
@@ -51,7 +61,11 @@ def _trained():
 
 def test_reference_form_removes_the_neighbour_choice_differences_on_the_trained_like_field():
     from oracle import convonet_oracle as O
-    same_blas = host_expanded_form_matches_torch()
+    # the trajectory fixtures come from the fixture host; the strict branch is pinned to ITS arithmetic (a committed tensor), not to
+    # the BLAS of the host that runs this test
+    assert fixture_host_expanded_form_matches_restatement(), "knn_ref_dist.npz no longer matches the restatement: regenerate the fixtures"
+    print("BRANCH: strict (pinned to tests/golden/knn_ref_dist.npz); this host's torch.matmul sums a 3-term dot like the restatement: %s"
+          % host_expanded_form_matches_torch())
     r, f, planes, w_np = _trained()
     try:
         for t in (0, 9, 99, 299, 499):
@@ -68,15 +82,7 @@ def test_reference_form_removes_the_neighbour_choice_differences_on_the_trained_
                                  float(np.abs(g - g_ref).max() / np.abs(g_ref).max()))
             print("trained-like t=%d: coordinates of x_next off by > 1e-6 / points whose gradient differs by > 5e-6 of max / largest gradient "
                   "difference: exact 5-NN %s, reference-form kNN %s" % (t + 1, res[False], res[True]))
-            if same_blas:
-                assert res[True][0] == 0 and res[True][1] == 0 and res[True][2] < 5e-6, (t, res[True])      # no exclusions
-            else:
-                # the fixtures were made on a host whose BLAS sums the three products of a dot in another order than this one's (or
-                # than the kernel's restatement): candidates within that noise may still swap
-                assert res[True][0] <= res[False][0] and res[True][1] <= res[False][1] + 2, (t, res)
-        if not same_blas:
-            print("NOTE: this host's torch.matmul does not sum a 3-term dot product as fma(z, z', fma(y, y', x x')): the bit-for-bit part "
-                  "of this test was relaxed (see host_expanded_form_matches_torch)")
+            assert res[True][0] == 0 and res[True][1] == 0 and res[True][2] < 5e-6, (t, res[True])      # no exclusions, always
         # what the difference costs after a whole run: exact 5-NN vs the reference's choice, 501 steps + normalisation, 8 clouds
         init = torch.from_numpy(f["init_points"])
         a = r.optimize_points(init, planes, rep_weight=500.0, iterations=500).cpu().numpy()
@@ -120,7 +126,8 @@ def test_reference_form_on_config5_sparse_inputs(np_weights, oracle_weights, gol
                            lambda q: O.optimize_points(oracle_weights, q, pd, rep_weight=500.0, iterations=9, loss_batch=B,
                                                        normalize=False).numpy(), 9, B, ox)
         print("config #5 K=256 + SOR, optimiser alone, 10 steps: points beyond 1e-3 / max / median vs the oracle: exact 5-NN %s, "
-              "reference-form kNN %s; the oracle vs its own 1-ulp-perturbed runs: %s" % (n[False], n[True], floor))
+              "reference-form kNN %s; the oracle vs its own 1-ulp-perturbed runs: %s (oracle run LIVE on this host; its matmul sums a "
+              "3-term dot like the kernel's restatement: %s)" % (n[False], n[True], floor, host_expanded_form_matches_torch()))
         assert n[True][0] <= max(floor), (n, floor)
         assert n[True][0] <= n[False][0]
     finally:

@@ -958,7 +958,8 @@ def _attribute_config(restorer, oracle_weights, prep, hip, iterations, tag):
     return n_opt, floor
 
 
-def test_config3_knn_attack_like_clouds(restorer, golden, oracle_weights):
+@pytest.mark.both_precisions
+def test_config3_knn_attack_like_clouds(restorer, golden, oracle_weights, precision_mode):
     """BASELINE config #3: perturbed clouds with tight clusters (the stress case of the neighbour lists)."""
     from oracle import convonet_oracle as O
     import bench
@@ -987,7 +988,8 @@ def test_config3_knn_attack_like_clouds(restorer, golden, oracle_weights):
     assert c["knn_rebuilds"] / (4 * 8) < 60, c                                 # ...instead of forcing whole-cloud rebuilds
 
 
-def test_config5_sparse_inputs(restorer, golden, oracle_weights):
+@pytest.mark.both_precisions
+def test_config5_sparse_inputs(restorer, golden, oracle_weights, precision_mode):
     """BASELINE config #5: Drop-200 (K = 824) and K = 256 inputs -> 1024 restored points each."""
     import bench
     for clouds in (bench.drop_like(golden["raw"]), bench.subsample_like(golden["raw"], 256)):
@@ -1011,7 +1013,8 @@ def test_config5_sparse_inputs(restorer, golden, oracle_weights):
             _attribute_config(restorer, oracle_weights, prep, hip, 9, "config #5 K=%d sor=%s" % (clouds.shape[1], sor))
 
 
-def test_attribution_on_sixteen_bench_clouds_twenty_steps(restorer, oracle_weights):
+@pytest.mark.both_precisions
+def test_attribution_on_sixteen_bench_clouds_twenty_steps(restorer, oracle_weights, precision_mode):
     """The attribution protocol (block comment above _oracle_trace) on a wider base than the 4-cloud fixtures: sixteen bench
     clouds - every shape family at least twice - through the build's own SOR / preprocess / encoder, 20 free-running Adam steps of the
     optimiser against the oracle on the same planes.  Every separating point explained, the count beyond 1e-3 within the oracle's
@@ -1105,7 +1108,8 @@ def _chamfer(a, b):
     return float(d.min(1).values.mean() + d.min(0).values.mean())
 
 
-def test_p3_full_501_steps_against_oracle(restorer, golden, oracle_weights, planes2):
+@pytest.mark.both_precisions
+def test_p3_full_501_steps_against_oracle(restorer, golden, oracle_weights, planes2, precision_mode):
     """Protocol P3: the 501-step trajectory is chaotic, so compare what is comparable - the share of
     points within 1e-3 next to the oracle's own 1-ulp self-divergence, the final losses, and the symmetric Chamfer
     distance build<->oracle against oracle<->perturbed oracle."""
@@ -1145,14 +1149,15 @@ def test_p3_full_501_steps_against_oracle(restorer, golden, oracle_weights, plan
     np.testing.assert_allclose(loss[:, 1].mean() * 500.0, float(rep), rtol=tol_rep)
 
 
-def test_full_size_properties(restorer):
+@pytest.mark.both_precisions
+def test_full_size_properties(restorer, precision_mode):
     """BASELINE size (2468 clouds x 1024 points x 501 steps): size-independent properties."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     import ifdefense_amd as I
     clouds = bench.synth_clouds(2468)
-    args = I.DefenseArgs(iterations=500, seed=1234)
+    args = I.DefenseArgs(iterations=500, seed=1234, precision=precision_mode)
     full = I.defend_point_cloud(restorer, clouds, args)
     assert full.shape == (2468, 1024, 3) and np.isfinite(full).all()
     np.testing.assert_allclose(np.linalg.norm(full, axis=-1).max(axis=1), 1.0, rtol=1e-5)       # unit sphere
@@ -1325,7 +1330,8 @@ def test_onet_end_to_end_and_sharding(onet, og, golden):
         onet.encode_points(torch.zeros(1, 300, 3))
 
 
-def test_onet_config1_pipeline_16_clouds(onet):
+@pytest.mark.both_precisions
+def test_onet_config1_pipeline_16_clouds(onet, precision_mode):
     """BASELINE config #1: ONet-Opt on 16 clean 1024-point clouds, 50 iterations - the whole driver
     (SOR -> preprocess / 300-point subset -> encoder -> init -> optimiser -> normalise) against the oracle fed
     with the same draws, plus sharding invariance."""
@@ -1359,13 +1365,33 @@ def test_onet_config1_pipeline_16_clouds(onet):
                                                                                normalize=False).numpy(), 9, 16, ox[-1])
     print("ONet config #1: points beyond 1e-3 after 10 steps: build vs oracle %d, oracle vs its 1-ulp-perturbed runs %s" % (n_opt, floor))
     assert n_opt <= max(floor) + 5, (n_opt, floor)
-    args = I.DefenseArgs(iterations=50, input_npoint=300, seed=21)
+    args = I.DefenseArgs(iterations=50, input_npoint=300, seed=21, precision=precision_mode)
     full = I.defend_point_cloud(onet, clouds, args)
     assert full.shape == (16, 1024, 3) and np.isfinite(full).all()
     np.testing.assert_allclose(np.linalg.norm(full, axis=-1).max(axis=1), 1.0, rtol=1e-6)
     lo = I.defend_point_cloud(onet, clouds[:5], args, cloud_index_base=0, total_clouds=16)
     hi = I.defend_point_cloud(onet, clouds[5:], args, cloud_index_base=5, total_clouds=16)
     assert np.array_equal(np.concatenate([lo, hi]), full)
+
+
+def test_onet_partial_round_first_and_overlap_are_bit_identical(onet):
+    """pipeline.defend_stream(tail_first / overlap) on the ONet restorer with n > CUs (round-5 advisor): the optimiser of one pass reads
+    its folded CBN coefficients for the whole launch while ifd_onet_encode of the next pass runs on the second stream - they used to
+    share the encoder scratch (api.cpp onet_fold; now a buffer of its own).  Enough steps that late-starting workgroups read their
+    coefficients long after the other stream's encoder has started."""
+    import bench
+    import ifdefense_amd as I
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    a = bench.synth_clouds(n_cu + 44, seed=70)
+    b = bench.synth_clouds(n_cu + 9, seed=71)
+    args = I.DefenseArgs(iterations=5, batch_size=192, seed=3, input_npoint=300)
+    ref = [o.clone() for o in I.defend_stream(onet, [a, b], args, bases=[0, 1000], totals=[len(a), 1000 + len(b)],
+                                             overlap=False, tail_first=False)]
+    for overlap in (False, True):
+        for _ in range(2):
+            got = [o.clone() for o in I.defend_stream(onet, [a, b], args, bases=[0, 1000], totals=[len(a), 1000 + len(b)],
+                                                     overlap=overlap, tail_first=True)]
+            assert len(got) == 2 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), overlap
 
 
 def test_onet_cli_end_to_end(tmp_path):
@@ -1796,8 +1822,9 @@ def test_rccl_path_under_torchrun(tmp_path):
     assert line["config"]["clouds_total"] == 70 and line["config"]["clouds_per_gpu"] == 70
 
 
+@pytest.mark.both_precisions
 @pytest.mark.parametrize("k", [6, 7, 16, 17, 33, 48, 49, 100, 333, 777, 1023])
-def test_optimise_point_count_sweep(restorer, golden, planes2, oracle_weights, k):
+def test_optimise_point_count_sweep(restorer, golden, planes2, oracle_weights, k, precision_mode):
     """Every boundary of the kernel's blocking: K = 6 is the smallest cloud with five neighbours, 16 / 32 the decoder's
     sub-tile / tile, 48 the neighbour-list length, 1023 one short of the maximum.  Six free-running steps against the
     oracle (tolerance of P2: 1e-3 after 10 steps; here 1e-4 after 6), with a teacher-forced single step at 1e-6."""
@@ -1893,7 +1920,8 @@ def trained():
     r.close()
 
 
-def test_trained_like_decoder_and_hot_gradient(trained):
+@pytest.mark.both_precisions
+def test_trained_like_decoder_and_hot_gradient(trained, precision_mode):
     r, f, planes, w_np = trained
     p = torch.from_numpy(f["init_points"])
     logits, grad = r.decode(p, planes, want_grad=True)
@@ -1944,7 +1972,8 @@ def test_trained_like_decoder_and_hot_gradient(trained):
     assert quirks[500] >= quirks[100]
 
 
-def test_trained_like_free_running_and_losses(trained):
+@pytest.mark.both_precisions
+def test_trained_like_free_running_and_losses(trained, precision_mode):
     r, f, planes, w_np = trained
     init = torch.from_numpy(f["init_points"])
     out10 = r.optimize_points(init, planes, rep_weight=500.0, iterations=9, normalize=False).cpu().numpy()
@@ -1978,7 +2007,8 @@ def test_trained_like_free_running_and_losses(trained):
     np.testing.assert_allclose(np.linalg.norm(out, axis=-1).max(axis=1), 1.0, rtol=1e-6)
 
 
-def test_trained_like_pipeline_lists_and_split(trained):
+@pytest.mark.both_precisions
+def test_trained_like_pipeline_lists_and_split(trained, precision_mode):
     """The whole path on the trained-like field from the fixture's recorded draws, and the kernel-level invariants in the
     regime where the points settle on a surface: certified lists == exact scan, split == one workgroup per cloud."""
     r, f, planes, _ = trained

@@ -283,3 +283,30 @@ def test_reference_knn_restated_to_the_bit():
     _, top = v.topk(6, dim=-1)
     for r in range(48):
         assert _ref_topk6_restated(v[r].numpy()) == top[r].tolist(), r
+
+
+def test_reference_knn_distance_matrix_fixture_pins_the_restatement():
+    """tests/golden/knn_ref_dist.npz holds the matrix the REFERENCE's knn_point handed to topk on the fixture host (captured inside
+    pn_utils.py:64-83 by tests/golden/make_knn_ref_dist.py; near-tie cluster + a coincident pair included) and the indices it
+    returned: the numpy restatement of the kernel's accumulation order reproduces the matrix bit for bit, and the restated
+    partial_sort selection (`_ref_topk6_restated`) its neighbour indices - on any host, no BLAS involved."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "knn_ref_dist.npz"))
+    x, dist, idx = z["pc"], z["dist"], z["idx"]
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    xi, xj = x[:, :, None, :], x[:, None, :, :]
+    dot = fma(xi[..., 2], xj[..., 2], fma(xi[..., 1], xj[..., 1], xi[..., 0] * xj[..., 0]))
+    sq = [x[..., k] * x[..., k] for k in range(3)]
+    xxn = (sq[0] + sq[1]) + sq[2]
+    mine = (xxn[:, None, :] + np.float32(-2.0) * dot) + xxn[:, :, None]
+    assert np.array_equal(mine, dist)
+    nd = -dist
+    quirk = 0
+    for b in range(nd.shape[0]):
+        for i in range(nd.shape[1]):
+            top6 = _ref_topk6_restated(nd[b, i])
+            assert top6[1:] == idx[b, i].tolist(), (b, i)
+            quirk += int(i in top6[1:])                 # "self" kept as a neighbour (column 0 was another point)
+    assert quirk >= 1, quirk                             # the coincident pair exercises the reference's column-0 quirk
