@@ -131,13 +131,42 @@ def host_cpu_model():
     return "unknown"
 
 
-def kernel_source_sha():
-    """Hash of the optimiser kernel's sources (the stamp scripts/summarise_profiles.py puts on roofline_traffic.json)."""
+def kernel_source_sha(precision="f32"):
+    """Hash of the optimiser kernel's sources (the stamp scripts/summarise_profiles.py puts on roofline_traffic*.json)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("optimize.hip", "optimize_kernel.h", "knn_device.h", "ifd_device.h"):
+    files = ("optimize.hip", "optimize_kernel.h", "knn_device.h", "ifd_device.h")
+    if precision != "f32":
+        files += ("optimize_bf.hip", "tile_bf.h", "split_bf16.h")
+    for f in files:
         h.update(open(os.path.join(ROOT, "if-defense_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def launch_shapes_of(ev, flop_per_cloud):
+    """[(clouds, mean ms, fraction of the f32-MFMA peak)] of the optimiser launches in `ev` ((event, event, clouds) triples), largest first."""
+    shapes = {}
+    for e0, e1, n_ in ev:
+        shapes.setdefault(n_, []).append(e0.elapsed_time(e1))
+    return [{"clouds": n_, "ms": round(sum(v) / len(v), 2),
+             "frac": round(flop_per_cloud * n_ / (sum(v) / len(v) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+            for n_, v in sorted(shapes.items(), reverse=True)]
+
+
+def traffic_from_profiles(precision, clouds_per_file, launches_per_file):
+    """HBM-side bytes per average launch from the PMC passes committed under profiles/ (counters cannot be read inside this run):
+    quoted only if they were measured on THIS kernel (source hash), this file size and this launch scheme - else None + the reason."""
+    name = "roofline_traffic.json" if precision == "f32" else "roofline_traffic_%s.json" % precision
+    tf = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(tf) or abs(clouds_per_file - N_CLOUDS) > 0.5:
+        return None, None, None
+    tj = json.load(open(tf))
+    if tj.get("kernel_source_sha") == kernel_source_sha(precision) and tj.get("launches_per_file", 1) == launches_per_file:
+        return (tj.get("optimize_kernel_hbm_bytes_per_launch"),
+                "profiles/%s (rocprofv3 PMC passes of this kernel, fetch factor %.2f; %g launch(es) per file, bytes per average launch; "
+                "FETCH_SIZE counts L2 -> fabric requests: Infinity-Cache hits are inside it)" % (name, tj.get("fetch_factor", 2.0), launches_per_file),
+                tj.get("launch_shapes"))
+    return None, "profiles/%s is from another build of the kernel or another launch scheme - not quoted" % name, None
 
 
 def cpu_baseline(clouds, n_sample=16, budget_s=15.0, onet=False, full_run_clouds=0):
@@ -220,6 +249,30 @@ def _cpu_worker_cold(job):
     return (time.perf_counter() - t0) / steps
 
 
+def cpu_baseline_pick(base):
+    """ONE `cpu_baseline.value` (round-5 verdict): the WHOLE HOST - cores // 16 oracle processes of 16 threads side by side, the
+    sampling in which the reference's loop uses the box best - with the once-per-cloud pre-processing of the single-process sample
+    added; the other samplings (one 16-thread process; 4 clouds unscaled; one B = 192 batch on all threads) stay beside it."""
+    sat = base.get("host_saturating", {}).get("workers_x16_threads", {})
+    if "value" not in sat:
+        base["definition"] = "one 16-thread oracle process (the host-saturating sampling failed: %s)" % sat.get("error", "?")
+        return base
+    single = {k: base[k] for k in ("value", "cores", "sample") if k in base}
+    try:
+        m = re.search(r"once \(([0-9.]+) s\)", base["sample"])
+        t_pre_per_cloud = float(m.group(1)) / 16.0
+    except Exception:      # noqa: BLE001
+        t_pre_per_cloud = 0.0
+    v = 1.0 / (1.0 / sat["value"] * 1.0 + t_pre_per_cloud / max(1, sat.get("workers", 1)))
+    base["other_samplings"] = {"one_process_16_threads": single, "full_run_4_clouds": base.pop("full_run", None),
+                               "batch192_all_threads": base["host_saturating"].get("batch192_all_threads")}
+    base.pop("host_saturating", None)
+    base.update({"value": round(v, 4), "cores": sat["cores"], "sample": sat["sample"] + "; + SOR / preprocess / encoder once per cloud from the "
+                 "one-process sample", "definition": "THE cpu_baseline: the whole host, %d oracle processes x 16 threads (other_samplings: "
+                 "smaller or differently batched samples of the same loop - they differ by up to 30 %% and are not the baseline)" % sat.get("workers", 0)})
+    return base
+
+
 def cpu_baseline_saturating(base, budget_s=20.0):
     """Two host-SATURATING figures next to the 16-thread one (round-4 verdict): (i) floor(cores / 16) concurrent 16-thread workers on
     disjoint 16-cloud batches, (ii) the reference's own batch of 192 clouds in ONE process at os.cpu_count() threads (BASELINE.md
@@ -259,37 +312,101 @@ def cpu_baseline_saturating(base, budget_s=20.0):
     return out
 
 
-def split_precision_extras(r, x, args, lo, total, ev):
-    """the whole path with the decoder's dense layers on the bf16 matrix core (ifd_opt_params.precision, csrc/tile_bf.h),
-    two files each, one at a time like the headline.  bf16x6 = both operands split exactly into three bf16 pieces, six piece products:
-    f32-equivalent arithmetic (held to the f32 tile's bars in tests/test_gpu_split_precision.py); bf16x3 = REDUCED precision.
-    Neither is the headline."""
+def timed_files(r, x, args, lo, total, ev, n_files, warm=1):
+    """`n_files` files one at a time (a device synchronisation after each, like the headline), after `warm` untimed ones:
+    (seconds per file, the optimiser launches' events of the timed files)."""
     import ifdefense_amd as I
+    for _ in I.defend_stream(r, [x] * warm, args, bases=[lo] * warm, totals=[total] * warm, overlap=False):
+        torch.cuda.synchronize()
+    ev.clear()
+    t0 = time.perf_counter()
+    for _ in I.defend_stream(r, [x] * n_files, args, bases=[lo] * n_files, totals=[total] * n_files, overlap=False):
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_files, list(ev)
+
+
+def f32_equivalent_block(r, x, args, lo, total, ev, n_files=4):
+    """The SAME workload with the decoder's dense layers on the bf16 matrix core, every operand split exactly into three bf16 pieces,
+    six piece products, f32 accumulation (ifd_opt_params.precision = 1, "bf16x6"; csrc/tile_bf.h): f32-EQUIVALENT arithmetic - its
+    error against float64 equals the f32 MFMA chain's, and the whole GPU parity matrix runs in this mode at the f32 bars
+    (tests/conftest.py `both_precisions`).  Reported beside the headline, never in its place (round-5 verdict, item 1)."""
+    import dataclasses
+    a6 = dataclasses.replace(args, precision="bf16x6")
+    dt, evs = timed_files(r, x, a6, lo, total, ev, n_files)
+    ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+    clouds = [n for _, _, n in evs]
+    avg_ms, avg_clouds = sum(ms) / len(ms), sum(clouds) / len(clouds)
+    achieved = FLOP_DENSE_PER_CLOUD * avg_clouds / (avg_ms * 1e-3) / 1e12
+    launches_per_file = len(ms) / float(n_files)
+    traffic, src, shapes_t = traffic_from_profiles("bf16x6", sum(clouds) / float(n_files), launches_per_file)
+    return {"mode": "bf16x6", "value": round(total / dt, 2), "unit": "clouds/s", "files_timed": n_files, "ms_per_file": round(dt * 1e3, 2),
+            "dtype": "bf16x6 (f32-equivalent: three exact bf16 pieces per operand, six products on v_mfma_f32_16x16x32_bf16, f32 accumulation)",
+            "roofline": {"bound": "mfma", "kernel": "ifd::optimize_kernel<8, S, 1>", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s (f32-equivalent: algorithmic decoder FLOPs; the matrix core executes 6x as many bf16 FLOPs, its dense "
+                                 "bf16 peak is ~2500)", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": src, "traffic_launch_shapes": shapes_t, "launch_ms": round(avg_ms, 2), "clouds_per_launch": avg_clouds,
+                         "launches_per_file": launches_per_file, "launch_shapes": launch_shapes_of(evs, FLOP_DENSE_PER_CLOUD)},
+            "parity": "tests/test_gpu_parity.py (the `both_precisions` tests: configs #3 / #5 attribution, 16 clouds x 20 steps, P3 501 steps, "
+                      "full size 2468 x 501 with bitwise re-runs, point-count sweep, large clouds, trained-like to t = 500, ONet config #1) and "
+                      "tests/test_gpu_split_precision.py - all at the f32 path's own bars",
+            "what": "the headline workload, driver and timing, only ifd_opt_params.precision differs; opt-in (--precision bf16x6), not the metric"}
+
+
+def split_precision_extras(r, x, args, lo, total, ev):
+    """SURVEY 8f row N4, the REDUCED mode: bf16x3 = two bf16 pieces per operand, three products (2^-17 per product) - characterised in
+    tests/test_gpu_split_precision.py, never the headline.  (bf16x6, the f32-equivalent mode, has its own block: `f32_equivalent`.)"""
+    import dataclasses
     out = {}
-    for mode in ("bf16x6", "bf16x3"):
-        os.environ["IFD_PRECISION"] = mode
-        try:
-            for _ in I.defend_stream(r, [x], args, bases=[lo], totals=[total], overlap=False):
-                pass
-            torch.cuda.synchronize()
-            ev.clear()
-            t0 = time.perf_counter()
-            for _ in I.defend_stream(r, [x] * 2, args, bases=[lo] * 2, totals=[total] * 2, overlap=False):
-                torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 2
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) / 2.0           # per FILE: the sum of its launches (partial round + whole rounds)
-            out[mode] = {"value": round(total / dt, 1), "unit": "clouds/s", "ms_per_file": round(dt * 1e3, 1), "optimiser_launch_ms": round(ms, 1),
+    try:
+        dt, evs = timed_files(r, x, dataclasses.replace(args, precision="bf16x3"), lo, total, ev, 2)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / 2.0          # per FILE: the sum of its launches (partial round + whole rounds)
+        out["bf16x3"] = {"value": round(total / dt, 1), "unit": "clouds/s", "ms_per_file": round(dt * 1e3, 1), "optimiser_launch_ms": round(ms, 1),
                          "f32_equivalent_tflops": round(FLOP_DENSE_PER_CLOUD * total / (ms * 1e-3) / 1e12, 1),
-                         "precision": "f32-equivalent (three exact bf16 pieces per operand, six products, f32 accumulation)" if mode == "bf16x6"
-                                      else "REDUCED (two pieces, three products: 2^-17 per product)"}
-        except Exception as e:      # noqa: BLE001
-            out[mode] = {"error": str(e)[:200]}
-        finally:
-            os.environ.pop("IFD_PRECISION", None)
-    out["what"] = ("opt-in arithmetic of the decoder's 32 x 32 layers, never the headline: one 2468-cloud file at a time, mean of 2; "
-                   "optimiser_launch_ms = the file's optimiser launches together; f32_equivalent_tflops = algorithmic decoder FLOPs / that time "
-                   "(the f32-MFMA peak is 157.3)")
+                         "precision": "REDUCED (two pieces, three products: 2^-17 per product)"}
+    except Exception as e:      # noqa: BLE001
+        out["bf16x3"] = {"error": str(e)[:200]}
+    out["what"] = ("opt-in REDUCED-precision arithmetic of the decoder's 32 x 32 layers, never the headline: one 2468-cloud file at a time, mean "
+                   "of 2; optimiser_launch_ms = the file's optimiser launches together")
     return out
+
+
+def trained_like_full(dev, n=N_CLOUDS, n_files=2):
+    """Round-5 verdict, item 6: a headline-SHAPED run on the realistic field - 2468 clouds, all seven bench families interleaved (one in
+    seven an airplane the checkpoint never saw), the trained-like checkpoint (tests/golden/trained_like_f16.npz), the WHOLE pipeline one
+    file at a time - with the launch shapes and the neighbour-list counters of the last file."""
+    import ifdefense_amd as I
+    z = np.load(os.path.join(ROOT, "tests", "golden", "trained_like_f16.npz"))
+    r = I.Restorer(I.weights.pack_state_dict({k: z[k].astype(np.float32) for k in z.files}), device=dev)
+    try:
+        x = torch.from_numpy(synth_clouds(n)).to(dev)
+        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234)
+        ev = []
+        orig = r.optimize_points
+
+        def timed(*p, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = orig(*p, **k)
+            e1.record()
+            ev.append((e0, e1, o.shape[0]))
+            return o
+
+        r.optimize_points = timed
+        dt, evs = timed_files(r, x, args, 0, n, ev, n_files)
+        c = r.counters()                                           # of the last launch: the file's whole rounds
+        last_n = evs[-1][2]
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+        clouds = [k for _, _, k in evs]
+        achieved = FLOP_DENSE_PER_CLOUD * (sum(clouds) / len(clouds)) / (sum(ms) / len(ms) * 1e-3) / 1e12
+        return {"value": round(n / dt, 1), "unit": "clouds/s (whole path, one file at a time)", "ms_per_file": round(dt * 1e3, 1),
+                "roofline_frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "launch_shapes": launch_shapes_of(evs, FLOP_DENSE_PER_CLOUD),
+                "list_rebuilds_per_cloud": round(c["knn_rebuilds"] / 8.0 / last_n, 2),
+                "ring_use_fraction": round(c["knn_ring_evals"] / (8.0 * last_n * (ITERATIONS + 1)), 3),
+                "exact_query_fraction": round(c["knn_exact_evals"] / (8.0 * last_n * (ITERATIONS + 1)), 4),
+                "what": "%d clouds of all SEVEN bench families, trained-like checkpoint, SOR + preprocess + encode + init + 501 Adam steps + "
+                        "normalise, %d files timed one at a time (f32); counters of the last file's whole-rounds launch" % (n, n_files)}
+    finally:
+        r.close()
 
 
 def extras(dev):
@@ -394,7 +511,7 @@ def extras(dev):
         r = I.Restorer(w, device=dev)
         x = torch.from_numpy(synth_clouds(256)).to(dev)
         per = {}
-        for k_opt, steps in ((1024, 51), (2048, 11)):
+        for k_opt, steps in ((1024, 101), (2048, 101)):
             prep = r.prepare(x, r.sor(x), n_sel=600, n_opt=k_opt, seed=1234)
             planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
             r.optimize_points(prep["init"][:8], planes[:8], rep_weight=500.0, steps=2)
@@ -403,10 +520,14 @@ def extras(dev):
             r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps)
             torch.cuda.synchronize()
             per[k_opt] = (time.perf_counter() - t0) / (256.0 * k_opt * steps)
+            ck = r.counters()
         out["k2048"] = {"value": round(1.0 / (per[2048] * 2048 * (ITERATIONS + 1)), 2), "unit": "clouds/s (2048 optimised points each, optimiser only)",
                         "per_point_cost_vs_1024": round(per[2048] / per[1024], 2),
-                        "what": "ifd_optimize on 256 clouds x 2048 points (two launches per Adam step, exact brute-force 5-NN: DESIGN section 4.6), "
-                                "11 of 501 steps scaled; per_point_cost_vs_1024 = time per point and step over the persistent kernel's on 256 clouds x 1024"}
+                        "list_epochs_per_cloud": round(ck["knn_rebuilds"] / 256.0, 2),
+                        "exact_query_fraction": round(ck["knn_exact_evals"] / (256.0 * 2048 * 101), 5),
+                        "what": "ifd_optimize on 256 clouds x 2048 points (two launches per Adam step: the persistent kernel's decoder tile, then certified "
+                                "neighbour lists + repulsion + Adam: DESIGN section 4.6), 101 of 501 steps scaled (the first step of a launch builds the "
+                                "lists); per_point_cost_vs_1024 = time per point and step over the persistent kernel's on 256 clouds x 1024"}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["k2048"] = {"error": str(e)[:200]}
@@ -499,10 +620,6 @@ def main():
                          "as such in metric / dtype / config.arith and is not the BASELINE metric")
     a = ap.parse_args()
     a.no_overlap = not a.streamed
-    # the headline is f32 whatever the environment says (IFD_PRECISION is runtime.py's measurement hook)
-    os.environ.pop("IFD_PRECISION", None)
-    if a.profile_precision != "f32":
-        os.environ["IFD_PRECISION"] = a.profile_precision
     onet = a.workload == "onet-opt"
     if onet and a.clouds == N_CLOUDS:
         a.clouds = 256                                                  # one cloud per CU; ~3 s per step
@@ -540,11 +657,12 @@ def main():
     x = torch.from_numpy(my_clouds).to(dev)                             # resident in HBM before timing
     if onet:
         r = I.OnetRestorer(I.weights.pack_state_dict(I.weights.onet_random_state_dict(0), "onet"), device=dev)
-        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234, input_npoint=300)
+        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234, input_npoint=300, precision=a.profile_precision)
         flop_per_cloud = 2 * 2 * (10 * 256 * 256 + 4 * 256) * K_POINTS * (ITERATIONS + 1)     # 1.347 TFLOP
     else:
         r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device=dev)
-        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234)
+        # the headline is f32 whatever the environment says: the precision is passed explicitly (--profile-precision only for profiling runs)
+        args = I.DefenseArgs(iterations=ITERATIONS, seed=1234, precision=a.profile_precision)
         flop_per_cloud = FLOP_DENSE_PER_CLOUD
 
     # time the dominant kernel (the persistent optimiser) with events on the stream it is launched on
@@ -602,6 +720,35 @@ def main():
 
     kern_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
     kern_clouds = [n for _, _, n in ev]
+    main_ev = list(ev)
+    # BASELINE configs #3 / #5 are ONE file over the GPUs of a node (strong scaling).  A weak-scaling run with more than one rank
+    # therefore times that too, right behind the headline passes: ONE array of --clouds clouds sharded over the ranks (round-5 verdict)
+    strong = None
+    if world > 1 and a.scaling == "weak" and not onet:
+        s_lo, s_hi, s_per = D.shard_range(a.clouds, rank, world)
+        xs = x[:max(0, s_hi - s_lo)]
+
+        def strong_steps(k):
+            out_ = None
+            for local_out in I.defend_stream(r, [xs] * k, args, bases=[s_lo] * k, totals=[a.clouds] * k, overlap=False):
+                out_ = D.gather_shards(local_out, a.clouds, s_per)
+                torch.cuda.synchronize()
+            return out_
+
+        strong_steps(1)
+        barrier()
+        t1 = time.perf_counter()
+        so = strong_steps(a.steps)
+        barrier()
+        t_strong = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_strong, op=dist.ReduceOp.MAX)
+        assert so.shape == (a.clouds, K_POINTS, 3)
+        strong = {"value": round(a.clouds * a.steps / float(t_strong.item()), 2), "unit": "clouds/s", "scaling": "strong",
+                  "clouds_total": a.clouds, "clouds_per_gpu": s_per, "ms_per_step": round(float(t_strong.item()) / a.steps * 1e3, 2),
+                  "what": "ONE %d-cloud array sharded over the %d ranks (BASELINE configs #3 / #5), %d passes timed like the headline "
+                          "(barrier + synchronize on both sides, max over ranks); the shard's partial round is split over 2 / 4 CUs per cloud" %
+                          (a.clouds, world, a.steps)}
+    ev[:] = main_ev
     if rank == 0:
         avg_ms = sum(kern_ms) / len(kern_ms)
         avg_clouds = sum(kern_clouds) / len(kern_clouds)
@@ -611,22 +758,10 @@ def main():
         # a file is one launch, or two (pipeline.defend_stream tail_first: the partial round, then the whole rounds); `achieved` is
         # over ALL launches of the kernel (what rocprofv3's per-kernel average corresponds to), the shapes are listed next to it
         launches_per_file = len(kern_ms) / float(a.steps)
-        shapes = {}
-        for ms_, n_ in zip(kern_ms, kern_clouds):
-            shapes.setdefault(n_, []).append(ms_)
-        launch_shapes = [{"clouds": n_, "ms": round(sum(v) / len(v), 2),
-                          "frac": round(flop_per_cloud * n_ / (sum(v) / len(v) * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
-                         for n_, v in sorted(shapes.items(), reverse=True)]
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tf) and not onet and abs(sum(kern_clouds) / float(a.steps) - N_CLOUDS) < 0.5:
-            tj = json.load(open(tf))
-            if tj.get("kernel_source_sha") == kernel_source_sha() and tj.get("launches_per_file", 1) == launches_per_file:
-                traffic = tj.get("optimize_kernel_hbm_bytes_per_launch")
-                traffic_src = "profiles/roofline_traffic.json (rocprofv3 PMC passes of this kernel, fetch factor %.2f; %g launch(es) per file, " \
-                              "bytes per average launch)" % (tj.get("fetch_factor", 2.0), launches_per_file)
-            else:
-                traffic_src = "profiles/roofline_traffic.json is from another build of the kernel or another launch scheme - not quoted"
+        launch_shapes = launch_shapes_of(ev, flop_per_cloud)
+        traffic, traffic_src, traffic_shapes = (None, None, None)
+        if not onet:
+            traffic, traffic_src, traffic_shapes = traffic_from_profiles(a.profile_precision, sum(kern_clouds) / float(a.steps), launches_per_file)
         res = {
             "metric": "restored clouds/sec (1024-pt ModelNet40, %s 500 iters)" % ("ONet-Opt" if onet else "ConvONet-Opt"),
             "value": round(total * a.steps / dt, 2), "unit": "clouds/s", "n_gpus": world, "steps": a.steps,
@@ -642,16 +777,23 @@ def main():
                                  "partial last round go first and the other clouds' pre-processing runs under that round (pipeline.defend_stream tail_first)",
                        "arith": "f32 throughout; decoder layers on v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain); repulsion terms' "
                                 "sqrt / 1/h / 1/d / exp through the 1-ulp hardware instructions (IFD_EXACT_REP off; libifd_exact.so has the "
-                                "IEEE expansions, +1.3 %); ReLU'(+0.0) passes in the hot tile (DESIGN section 10)"},
+                                "IEEE expansions, +1.3 %); ReLU'(+0.0) passes in the hot tile (DESIGN section 9); the 5-NN sets of the repulsion "
+                                "term are EXACT (direct differences, ties by index) where the reference's expanded-form float32 ranking swaps "
+                                "near-ties and keeps 'self' for pairs closer than ~1.5e-4 - ifd_opt_params.knn_reference_form reproduces that bug "
+                                "for bug (validation mode: with it config #5 K = 256 meets the 1e-3 bound inside the oracle's own 1-ulp floor, "
+                                "without it 7 of 4096 points exceed it after 10 steps; DESIGN section 9); the optimised points of a cloud are "
+                                "processed in Morton order of their initial coordinates (the reference's draw order is i.i.d.)"},
             "roofline": {"bound": "mfma", "kernel": "ifd::onet_optimize_kernel" if onet else "ifd::optimize_kernel",
                          "achieved": round(achieved, 2),
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(avg_ms, 2),
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_launch_shapes": traffic_shapes, "launch_ms": round(avg_ms, 2),
                          "clouds_per_launch": avg_clouds, "flop_per_cloud": flop_per_cloud,
                          "launches_per_file": launches_per_file, "launch_shapes": launch_shapes},
             "optimise_only_clouds_per_s": round(sum(kern_clouds) / (sum(kern_ms) * 1e-3), 2),
             "gather_ms": round(sum(g0.elapsed_time(g1) for g0, g1 in gev) / max(1, len(gev)), 3),
         }
+        if strong is not None:
+            res["strong_scaling"] = strong
         if a.profile_precision != "f32":
             # a profiling run of the opt-in split-precision mode: labelled so that it cannot be read as the BASELINE metric
             res["metric"] += " [PROFILING RUN, decoder layers %s - not the headline]" % a.profile_precision
@@ -676,11 +818,20 @@ def main():
             res["cpu_baseline"] = cpu_baseline(my_clouds, onet=onet, full_run_clouds=0 if onet else 4)
             if not onet:
                 res["cpu_baseline"]["host_saturating"] = cpu_baseline_saturating(res["cpu_baseline"])
+                res["cpu_baseline"] = cpu_baseline_pick(res["cpu_baseline"])
         if world == 1 and not onet and not a.no_extras:
             res["extras"] = extras(dev)
             if streamed is not None:
                 res["extras"]["streamed"] = streamed
+            try:
+                res["f32_equivalent"] = f32_equivalent_block(r, x, args, lo, total, ev)
+            except Exception as e:      # noqa: BLE001
+                res["f32_equivalent"] = {"error": str(e)[:200]}
             res["extras"]["split_precision"] = split_precision_extras(r, x, args, lo, total, ev)
+            try:
+                res["extras"]["trained_like_full"] = trained_like_full(dev)
+            except Exception as e:      # noqa: BLE001
+                res["extras"]["trained_like_full"] = {"error": str(e)[:200]}
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

@@ -702,7 +702,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: split must be 0 (automatic), 1, 2 or 4");
     if (prm->precision < 0 || prm->precision > 2)
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: precision must be 0 (f32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
-    a.precision = K > MAXK ? 0 : prm->precision;      // (clouds beyond 1024 points: the launch-per-step path has the f32 tile only)
+    a.precision = prm->precision;
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (optimize.hip)
     hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : optimize_ws_bytes(B));
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
@@ -712,8 +712,8 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
     if (large) {
-        e = launch_large_optimize(ctx->d_dec_img, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,
-                                  static_cast<const float*>(ctx->adam_tab), B, K, a, static_cast<hipStream_t>(stream));
+        e = launch_large_optimize(a.precision != 0 ? ctx->d_dec_img_bf : ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
+                                  ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K, a, ctx->n_cu, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
     }
     e = launch_optimize(a.precision != 0 ? ctx->d_dec_img_bf : ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,

@@ -916,8 +916,10 @@ __device__ __forceinline__ void normalize_in_lds(f32x4* __restrict__ X, int K, f
     const float cz = block_sum(a.z + b.z, scratch) / (float)K;
     a.x -= cx; a.y -= cy; a.z -= cz;
     b.x -= cx; b.y -= cy; b.z -= cz;
-    const float da = pa < K ? sqrtf(a.x * a.x + a.y * a.y + a.z * a.z) : 0.f;
-    const float db = pb < K ? sqrtf(b.x * b.x + b.y * b.y + b.z * b.z) : 0.f;
+    // (every multiply-add SPELLED: hipcc contracts a * a + b * b + c * c differently in different instantiations - the fused tail of
+    // the split-precision optimiser and the stand-alone kernel differed in the last bit of one cloud's radius, round 6)
+    const float da = pa < K ? sqrtf(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))) : 0.f;
+    const float db = pb < K ? sqrtf(__builtin_fmaf(b.z, b.z, __builtin_fmaf(b.y, b.y, b.x * b.x))) : 0.f;
     const float md = block_max(fmaxf(da, db), scratch);
     if (pa < K) X[pa] = f32x4{a.x / md, a.y / md, a.z / md, 0.f};
     if (pb < K) X[pb] = f32x4{b.x / md, b.y / md, b.z / md, 0.f};

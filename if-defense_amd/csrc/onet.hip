@@ -250,6 +250,7 @@ hipError_t launch_onet_large_optimize(const float* img, const float* small, cons
                                       const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {
     f32x4* G = static_cast<f32x4*>(ws);
     void* f_ws = nullptr;                  // global repulsion accumulators beyond LARGE_LDS_MAXK points (end of ws)
+    void* list_ws = large_list_ws(ws, B, K, m == nullptr);      // certified neighbour lists up to LARGE_LDS_MAXK points (optimize.hip)
     {
         hipError_t e = large_f_prepare(ws, B, K, m == nullptr, &f_ws, s);
         if (e != hipSuccess) return e;
@@ -266,7 +267,7 @@ hipError_t launch_onet_large_optimize(const float* img, const float* small, cons
         hipLaunchKernelGGL(onet_large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, p, K,
                            loss_batch_per_cloud, a.loss_batch, a.threshold, G);
         hipError_t e = launch_large_step(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a,
-                                         step == a.steps - 1 ? loss : nullptr, f_ws, counters, s);
+                                         step == a.steps - 1 ? loss : nullptr, f_ws, list_ws, counters, s);
         if (e != hipSuccess) return e;
     }
     return a.normalize ? launch_large_normalize(p, B, K, s) : hipGetLastError();

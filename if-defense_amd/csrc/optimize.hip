@@ -117,31 +117,6 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void normalize_kernel(float* __rest
 constexpr int LARGE_THREADS = 1024;
 constexpr int LARGE_PPT = (LARGE_MAXK + LARGE_THREADS - 1) / LARGE_THREADS + ((LARGE_MAXK + LARGE_THREADS - 1) / LARGE_THREADS & 1);   // points per thread: 10 (even)
 
-__global__ __launch_bounds__(OPT_THREADS, 2) void large_occupancy_kernel(const float* __restrict__ dec_img,
-                                                                          const float* __restrict__ planes,
-                                                                          const float* __restrict__ p, int K,
-                                                                          const int32_t* __restrict__ loss_batch_per_cloud,
-                                                                          int loss_batch, float thr,
-                                                                          f32x4* __restrict__ G, DecConst dc) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W = smem;
-    const int cloud = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    load_dec_image(W, dec_img);
-    __syncthreads();
-    const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
-    const float* pc = p + (size_t)cloud * K * 3;
-    const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
-    const float inv_lb = 1.0f / (float)lb;
-    const int ntiles = (K + 15) >> 4, nw = (int)(blockDim.x >> 6);
-    for (int tile = blockIdx.y * nw + wave; tile < ntiles; tile += (int)gridDim.y * nw) {
-        const int tp = min(tile * 16 + (lane & 15), K - 1);
-        const float x0 = pc[3 * tp], x1 = pc[3 * tp + 1], x2 = pc[3 * tp + 2];
-        float logit, bce, dx[3] = {0.f, 0.f, 0.f};
-        decoder_tile<MODE_OPT, true, 2>(W, pl, x0, x1, x2, lane, dc, thr, inv_lb, logit, bce, dx);
-        if (lane < 16 && tile * 16 + lane < K) G[(size_t)cloud * K + tp] = f32x4{dx[0], dx[1], dx[2], bce};
-    }
-}
-
 struct LargeLds {
     f32x4* X;
     RepAcc F;
@@ -185,14 +160,15 @@ __device__ __forceinline__ void large_take_f(const RepAcc F, int pt, int (&fi)[3
 
 // exact 5-NN + repulsion terms of the points of this thread, two at a time (the persistent kernel's rep_point2)
 __device__ __forceinline__ void large_knn_rep(const LargeLds& l, int K, const RepConst rc, float (&rep_l)[LARGE_PPT],
-                                              int32_t* __restrict__ knn_idx) {
+                                              int32_t* __restrict__ knn_idx, bool ref_form = false) {
     const int tid = threadIdx.x;
 #pragma unroll 1
     for (int r = 0; r < LARGE_PPT; r += 2) {
         if (r * LARGE_THREADS >= K) break;                                            // block-uniform
         const int pa = tid + r * LARGE_THREADS, pb = pa + LARGE_THREADS;
         Top5 ta, tb;
-        knn_scan2(l.X, K, pa, pb, ta, tb);
+        if (ref_form) knn_scan_ref2(l.X, K, pa, pb, ta, tb);        // validation: the reference's neighbour choice bug for bug (knn_device.h)
+        else knn_scan2(l.X, K, pa, pb, ta, tb);
         float la, lb;
         rep_point2(l.X, l.F, K, pa, pb, ta, tb, rc, la, lb);
         rep_l[r] = pa < K ? la : 0.f;
@@ -211,7 +187,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
                                                                     const int32_t* __restrict__ loss_batch_per_cloud,
                                                                     int loss_batch, float rep_weight, RepConst rc,
                                                                     float* __restrict__ loss_out, void* f_ws,
-                                                                    unsigned long long* status) {
+                                                                    unsigned long long* status, int ref_form) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     const LargeLds l = large_lds<GF>(smem, K, (int)gridDim.x, cloud, f_ws);
@@ -226,7 +202,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
     float rep_l[LARGE_PPT];
 #pragma unroll
     for (int r = 0; r < LARGE_PPT; ++r) rep_l[r] = 0.f;
-    if (rep_weight > 0.f) large_knn_rep(l, K, rc, rep_l, nullptr);
+    if (rep_weight > 0.f) large_knn_rep(l, K, rc, rep_l, nullptr, ref_form != 0);
     __syncthreads();
     const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
     const float rep_scale = rep_weight / ((float)lb * (float)K * 5.f);
@@ -262,6 +238,312 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
     if (loss_out != nullptr) {                                // losses at the pre-update points of this (the last) step
         occ = block_sum(occ, l.scratch);
         rep = block_sum(rep, l.scratch);
+        if (tid == 0) { loss_out[2 * cloud] = occ; loss_out[2 * cloud + 1] = rep / ((float)K * 5.f); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Certified neighbour lists of the launch-per-step path (1025 ... LARGE_LDS_MAXK points; round 6).
+//
+// large_step_kernel above ranks all K candidates for every point at every step: O(K^2), 2.5 x the per-point cost of the persistent
+// kernel at K = 2048.  The reference does the same (defense/pn_utils.py:72-83) - but the answer is the exact 5-NN set either way, and
+// between two steps a point moves by ~lr.  large_step_lists_kernel keeps, per point i, the LL_M-entry list of EVERY point that was
+// closer than rho_i when the list was built (global memory, 64 bytes per point), and certifies per step that the list still holds
+// the five nearest (same inequality as the persistent kernel's lists):
+//       r5 < rho_i - |x_i - x_i(t_i)| - (S(now) - S(t_i))
+// (a point outside the list was >= rho_i away at build time t_i and every point has moved by at most S(now) - S(t_i) since, S(t) = the
+// running sum of the per-step maxima max_j |x_j(s + 1) - x_j(s)|: no epochs, no second position array).  Evaluation: 32-bit keys
+// (distance bits | index) through the sorted top-6 network of knn_device.h - the five smallest keys are the five nearest list members
+// unless keys 5 and 6 tie above the index bits.
+//   * certificate holds, no tie: the five neighbours are the exact 5-NN; repulsion terms at once (rep_point2);
+//   * otherwise the point goes to an LDS queue; after a barrier the workgroup's 16 waves take the queued points one at a time: the
+//     lanes split the K candidates, per-lane sorted top-5, five rounds of a wave-wide (distance, index) minimum = the exact 5-NN in
+//     the scan's own order, then the point's list is rebuilt around it (rho^2 = 5 d5^2; 2.5 d5^2 if that ball overflows the list; a
+//     ball that still overflows leaves rho = 0: that point is resolved exactly every step) and its terms are added;
+//   * the first step of a call: every thread runs the exact scan for its points (knn_scan2: the brute-force kernel's code) and builds
+//     their lists itself.  There is NO later whole-cloud rebuild: the step is one launch for all clouds, so a rebuild of any one cloud
+//     would set the duration of that step for all of them (measured: epochs every ~7 steps per cloud made EVERY step an epoch step,
+//     profiles/r06_time_large_k.txt) - expiring lists are renewed one point at a time instead, a few per cent of the points per step.
+// Every path selects the five smallest (distance, index) pairs and the repulsion sums are fixed point: outputs are bit-identical to
+// large_step_kernel's (ifd_opt_params.knn_scan_every_step selects that kernel; tests/test_gpu_parity.py holds the two against each other).
+// ---------------------------------------------------------------------------------------------
+constexpr int LL_M = 32;                            // list entries per point
+constexpr unsigned int LL_IDX_MASK = 8191u;         // 13 index bits: 0 ... LARGE_LDS_MAXK (the dummy entry)
+constexpr int LL_DUMMY = LARGE_LDS_MAXK;            // X[LL_DUMMY]: a far-away point (unused list slots)
+constexpr float LL_ALPHA = 5.f;                     // rho^2 = LL_ALPHA d5^2: ~25 of the 32 entries on a surface, slack rho - r5 = 1.24 r5
+struct LargeLists {
+    uint16_t* lists;     // [B][K][LL_M]
+    f32x4* cert;         // [B][K]  {position at build time, rho}
+    float* dbase;        // [B][K]  S at build time
+    float* scal;         // [B][4]  S(now) = sum over the call's steps so far of max_j |x_j(s + 1) - x_j(s)|, -, -, -
+};
+size_t large_list_bytes(int B, int K) {
+    return K <= LARGE_LDS_MAXK ? (size_t)B * K * (LL_M * 2 + 16 + 4) + (size_t)B * 16 : 0;
+}
+static LargeLists large_lists_at(void* base, int B, int K) {
+    LargeLists L;
+    char* c = static_cast<char*>(base);
+    L.cert = reinterpret_cast<f32x4*>(c);                       c += (size_t)B * K * 16;
+    L.lists = reinterpret_cast<uint16_t*>(c);                   c += (size_t)B * K * LL_M * 2;
+    L.dbase = reinterpret_cast<float*>(c);                      c += (size_t)B * K * 4;
+    L.scal = reinterpret_cast<float*>(c);
+    return L;
+}
+constexpr size_t LARGE_LISTS_LDS = (size_t)(LARGE_LDS_MAXK + 1) * 16 + (size_t)LARGE_LDS_MAXK * (8 + 4 + 4 + 2) + 64 * 4 + 16;   // 139,552 B
+
+__device__ __forceinline__ float ll_dist2(const f32x4& a, const f32x4& b) {
+    const float ex = a.x - b.x, ey = a.y - b.y, ez = a.z - b.z;
+    return fmaf(ez, ez, fmaf(ey, ey, ex * ex));                  // knn_scan2's expression
+}
+// inclusive prefix sum over the wave (DPP inside the rows of 16, the row totals through readlane: knn_build_one's scheme)
+__device__ __forceinline__ int ll_wave_scan(int v, int lane, int& total) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
+    const int r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+    const int row = lane >> 4;
+    total = r0 + r1 + r2 + r3;
+    return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+}
+// one thread builds the list of its point i (first step): every j != i with |x_j - x_i|^2 < r2, r2 = 5 d5^2, or 2.5 d5^2 if that ball
+// holds more than LL_M points; returns rho (0: no valid list)
+__device__ __forceinline__ float ll_build_thread(const f32x4* __restrict__ X, int K, int i, float d5sq, uint16_t* __restrict__ lst) {
+    const f32x4 xi = X[i];
+    float rho = 0.f;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const float r2 = (attempt == 0 ? LL_ALPHA : 0.5f * LL_ALPHA) * d5sq;
+        int cnt = 0;
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) {
+            const float d = ll_dist2(X[j], xi);
+            if (d < r2 && j != i) {
+                if (cnt < LL_M) lst[cnt] = (uint16_t)j;
+                ++cnt;
+            }
+        }
+        if (cnt <= LL_M) {
+            for (int e = cnt; e < LL_M; ++e) lst[e] = (uint16_t)LL_DUMMY;
+            rho = sqrtf(r2);
+            break;
+        }
+    }
+    return rho;
+}
+// keys of the two points' lists (list_keys6_2 with 13 index bits and LL_M entries)
+__device__ __forceinline__ void ll_keys2(const f32x4* __restrict__ X, const uint16_t* __restrict__ La, const uint16_t* __restrict__ Lb,
+                                         int ia, int ib, Keys6& qa, Keys6& qb) {
+    const f32x4 xa = X[ia], xb = X[ib];
+    u32x4 wa[LL_M / 8], wb[LL_M / 8];
+#pragma unroll
+    for (int c = 0; c < LL_M / 8; ++c) {
+        wa[c] = reinterpret_cast<const u32x4*>(La)[c];
+        wb[c] = reinterpret_cast<const u32x4*>(Lb)[c];
+    }
+#pragma unroll
+    for (int c = 0; c < LL_M / 4; ++c) {                                                  // four entries of each list at a time
+        unsigned int ja[4], jb[4];
+        f32x4 pa_[4], pb_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int pka = wa[c >> 1][2 * (c & 1) + (e >> 1)], pkb = wb[c >> 1][2 * (c & 1) + (e >> 1)];
+            ja[e] = (e & 1) ? (pka >> 16) : (pka & 0xffffu);
+            jb[e] = (e & 1) ? (pkb >> 16) : (pkb & 0xffffu);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pa_[e] = X[ja[e]]; pb_[e] = X[jb[e]]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            keys6_insert(qa, (__float_as_uint(ll_dist2(pa_[e], xa)) & ~LL_IDX_MASK) | ja[e]);
+            keys6_insert(qb, (__float_as_uint(ll_dist2(pb_[e], xb)) & ~LL_IDX_MASK) | jb[e]);
+        }
+    }
+}
+// the five smallest keys as neighbour indices + whether they are certified to be the exact 5-NN of the point
+__device__ __forceinline__ bool ll_certify(const Keys6& q, const f32x4& x, const f32x4& cert, float dsum, Top5& t) {
+    t.i0 = (int)(q.k0 & LL_IDX_MASK); t.i1 = (int)(q.k1 & LL_IDX_MASK); t.i2 = (int)(q.k2 & LL_IDX_MASK);
+    t.i3 = (int)(q.k3 & LL_IDX_MASK); t.i4 = (int)(q.k4 & LL_IDX_MASK);
+    t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = 0.f;
+    const bool tie = ((q.k4 ^ q.k5) & ~LL_IDX_MASK) == 0u;
+    const float r5 = q.k4 >= 0x7f800000u ? INFINITY : sqrtf(__uint_as_float(q.k4 | LL_IDX_MASK));     // upper bound of the 5th distance
+    const float ex = x.x - cert.x, ey = x.y - cert.y, ez = x.z - cert.z;
+    const float moved = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+    // (strict, with room for the roundings of the three square roots and of D: all O(1e-7) relative)
+    return !tie && cert.w > 0.f && (r5 + moved + dsum) * 1.00001f + 1e-7f < cert.w;
+}
+
+__global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* __restrict__ p, float* __restrict__ m_io,
+                                                                          float* __restrict__ v_io, const f32x4* __restrict__ G,
+                                                                          int K, const float* __restrict__ adam_tab, int step,
+                                                                          const int32_t* __restrict__ loss_batch_per_cloud,
+                                                                          int loss_batch, float rep_weight, RepConst rc,
+                                                                          float* __restrict__ loss_out, LargeLists L,
+                                                                          unsigned long long* status) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4* X = reinterpret_cast<f32x4*>(smem);                                        // [LARGE_LDS_MAXK + 1]
+    long long* const fxy = reinterpret_cast<long long*>(X + LARGE_LDS_MAXK + 1);
+    const RepAcc Fz = {fxy, reinterpret_cast<int*>(fxy + LARGE_LDS_MAXK)};              // fixed-point repulsion sums (knn_device.h)
+    float* RL = reinterpret_cast<float*>(Fz.z + LARGE_LDS_MAXK);                      // [LARGE_LDS_MAXK] repulsion loss term of every point
+    float* scratch = RL + LARGE_LDS_MAXK;                                             // [64]
+    int* qn = reinterpret_cast<int*>(scratch + 64);                                   // queue length (+ 3 pad)
+    uint16_t* queue = reinterpret_cast<uint16_t*>(qn + 4);                            // [LARGE_LDS_MAXK]
+    const size_t cb = (size_t)cloud * K;
+    float* pc = p + cb * 3;
+    constexpr int PPT = LARGE_LDS_MAXK / LARGE_THREADS;                               // 4 points per thread
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+        if (pt < K) X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
+        Fz.xy[pt] = 0; Fz.z[pt] = 0; RL[pt] = 0.f;
+    }
+    if (tid == 0) { *qn = 0; X[LL_DUMMY] = f32x4{1e18f, 1e18f, 1e18f, 0.f}; }
+    const bool epoch = step == 0;                                                     // the call's first step: every list is built
+    const float d_now = epoch ? 0.f : L.scal[4 * cloud + 0];                          // S(now)
+    __syncthreads();
+    if (rep_weight > 0.f) {
+#pragma unroll 1
+        for (int r = 0; r < PPT; r += 2) {
+            if (r * LARGE_THREADS >= K) break;                                        // block-uniform
+            const int pa = tid + r * LARGE_THREADS, pb = pa + LARGE_THREADS;
+            const bool va = pa < K, vb = pb < K;
+            const int ia = min(pa, K - 1), ib = min(pb, K - 1);
+            Top5 ta, tb;
+            bool oka = va, okb = vb;
+            if (epoch) {
+                knn_scan2(X, K, pa, pb, ta, tb);
+                if (va) {
+                    const float rho = ll_build_thread(X, K, pa, ta.d4, L.lists + (cb + pa) * LL_M);
+                    const f32x4 x = X[pa];
+                    L.cert[cb + pa] = f32x4{x.x, x.y, x.z, rho};
+                    L.dbase[cb + pa] = 0.f;
+                }
+                if (vb) {
+                    const float rho = ll_build_thread(X, K, pb, tb.d4, L.lists + (cb + pb) * LL_M);
+                    const f32x4 x = X[pb];
+                    L.cert[cb + pb] = f32x4{x.x, x.y, x.z, rho};
+                    L.dbase[cb + pb] = 0.f;
+                }
+            } else {
+                Keys6 qa, qb;
+                keys6_init(qa);
+                keys6_init(qb);
+                ll_keys2(X, L.lists + (cb + ia) * LL_M, L.lists + (cb + ib) * LL_M, ia, ib, qa, qb);
+                oka = va && ll_certify(qa, X[ia], L.cert[cb + ia], (d_now - L.dbase[cb + ia]) * 1.00001f, ta);
+                okb = vb && ll_certify(qb, X[ib], L.cert[cb + ib], (d_now - L.dbase[cb + ib]) * 1.00001f, tb);
+                if (va && !oka) queue[atomicAdd(qn, 1)] = (uint16_t)pa;
+                if (vb && !okb) queue[atomicAdd(qn, 1)] = (uint16_t)pb;
+            }
+            float la, lb;
+            rep_point2(X, Fz, K, oka ? pa : K, okb ? pb : K, ta, tb, rc, la, lb);
+            if (oka) RL[pa] = la;
+            if (okb) RL[pb] = lb;
+        }
+        __syncthreads();
+        // ---- the queued points: exact 5-NN by the whole wave, list rebuilt, terms added ------------------------------------
+        const int nq = *qn;
+#pragma unroll 1
+        for (int qi = wave; qi < nq; qi += LARGE_THREADS / 64) {
+            const int i = queue[qi];
+            const f32x4 xi = X[i];
+            Top5 t;
+            top5_init(t);
+#pragma unroll 4
+            for (int j = lane; j < K; j += 64) {
+                const float d = j == i ? INFINITY : ll_dist2(X[j], xi);
+                top5_insert(t, d, j);                                                   // ascending j: ties keep the smaller index
+            }
+            Top5 res;
+            float rd[5];
+            int rj[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                float bd = t.d0;
+                int bj = t.d0 < INFINITY ? t.i0 : 0x7fffffff;
+                lexmin_wave(bd, bj);
+                rd[k] = bd;
+                rj[k] = bj;
+                if (bd < INFINITY && (bj & 63) == lane) {                               // the winner's lane pops its head
+                    t.d0 = t.d1; t.i0 = t.i1; t.d1 = t.d2; t.i1 = t.i2; t.d2 = t.d3; t.i2 = t.i3; t.d3 = t.d4; t.i3 = t.i4;
+                    t.d4 = INFINITY; t.i4 = 0;
+                }
+            }
+            res.d0 = rd[0]; res.d1 = rd[1]; res.d2 = rd[2]; res.d3 = rd[3]; res.d4 = rd[4];
+            res.i0 = rj[0]; res.i1 = rj[1]; res.i2 = rj[2]; res.i3 = rj[3]; res.i4 = rj[4];
+            // the point's new list
+            uint16_t* lst = L.lists + (cb + i) * LL_M;
+            float rho = 0.f;
+#pragma unroll 1
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const float r2 = (attempt == 0 ? LL_ALPHA : 0.5f * LL_ALPHA) * rd[4];
+                int cnt = 0;
+                for (int j = lane; j < K; j += 64) cnt += (j != i && ll_dist2(X[j], xi) < r2) ? 1 : 0;
+                int total;
+                const int incl = ll_wave_scan(cnt, lane, total);
+                if (total > LL_M) continue;                                             // wave-uniform
+                int at = incl - cnt;
+                for (int j = lane; j < K; j += 64)
+                    if (j != i && ll_dist2(X[j], xi) < r2) lst[at++] = (uint16_t)j;
+                if (lane >= total && lane < LL_M) lst[lane] = (uint16_t)LL_DUMMY;
+                rho = sqrtf(r2);
+                break;
+            }
+            if (lane == 0) {
+                L.cert[cb + i] = f32x4{xi.x, xi.y, xi.z, rho};
+                L.dbase[cb + i] = d_now;
+                float la, lb;
+                rep_point2(X, Fz, K, i, K, res, res, rc, la, lb);
+                RL[i] = la;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && status != nullptr) {                                            // diagnostics (ifd_get_counters)
+            if (epoch) atomicAdd(status + 0, 1ull);                                     // (whole-cloud list builds: one per cloud and call)
+            if (nq > 0) atomicAdd(status + 5, (unsigned long long)nq);
+        }
+    }
+    const int lb_ = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
+    const float rep_scale = rep_weight / ((float)lb_ * (float)K * 5.f);
+    const float step_size = adam_tab[2 * step], bc2 = adam_tab[2 * step + 1];
+    float occ = 0.f, rep = 0.f, moved = 0.f;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int pt = tid + r * LARGE_THREADS;
+        if (pt >= K) continue;
+        const f32x4 go = G[cb + pt];
+        const f32x4 x = X[pt];
+        const float gocc[3] = {go.x, go.y, go.z};
+        float xs[3] = {x.x, x.y, x.z};
+        int fi[3];
+        large_take_f<false>(Fz, pt, fi, status);
+        const size_t o = (cb + pt) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {                         // large_step_kernel's update, term by term
+            const float gn = (float)fi[a] * FIX32_INV;
+            const float g = __builtin_fmaf(gn, rep_scale, gocc[a]);
+            float mr = m_io[o + a], vr = v_io[o + a];
+            mr = __builtin_fmaf(g - mr, 1.f - 0.9f, mr);
+            vr = __builtin_fmaf((1.f - 0.999f) * g, g, vr * 0.999f);
+            const float denom = sqrtf(vr) / bc2 + 1e-8f;
+            xs[a] = __builtin_fmaf(-step_size, mr / denom, xs[a]);
+            m_io[o + a] = mr;
+            v_io[o + a] = vr;
+            pc[3 * pt + a] = xs[a];
+        }
+        occ += go.w;
+        rep += RL[pt];
+        // this step's move (an upper bound: rounded up a little)
+        const float ex = xs[0] - x.x, ey = xs[1] - x.y, ez = xs[2] - x.z;
+        moved = fmaxf(moved, sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * 1.00001f);
+    }
+    const float dmax = block_max(moved, scratch);
+    if (tid == 0) L.scal[4 * cloud + 0] = d_now + dmax;
+    if (loss_out != nullptr) {                                // losses at the pre-update points of this (the last) step
+        occ = block_sum(occ, scratch);
+        rep = block_sum(rep, scratch);
         if (tid == 0) { loss_out[2 * cloud] = occ; loss_out[2 * cloud + 1] = rep / ((float)K * 5.f); }
     }
 }
@@ -328,7 +610,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_normalize_kernel(float* _
         const int pt = tid + r * LARGE_THREADS;
 #pragma unroll
         for (int a = 0; a < 3; ++a) x[r][a] -= c[a];
-        if (pt < K) dm = fmaxf(dm, sqrtf(x[r][0] * x[r][0] + x[r][1] * x[r][1] + x[r][2] * x[r][2]));
+        if (pt < K) dm = fmaxf(dm, sqrtf(__builtin_fmaf(x[r][2], x[r][2], __builtin_fmaf(x[r][1], x[r][1], x[r][0] * x[r][0]))));     // (normalize_in_lds's form)
     }
     const float md = block_max(dm, scratch);
 #pragma unroll
@@ -378,8 +660,11 @@ hipError_t configure_optimize_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_occupancy_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_occupancy3_kernel<0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_step_lists_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_LISTS_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_step_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_LDS);
@@ -494,8 +779,14 @@ hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* gr
     return hipGetLastError();
 }
 
-size_t large_ws_bytes(int B, int K, bool own_moments) {
-    return (size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0) + large_f_bytes(B, K);
+// workspace of the launch-per-step path: [G: B K float4 | own moments (if the caller passes none) | global repulsion accumulators
+// (K > LARGE_LDS_MAXK) | certified neighbour lists (K <= LARGE_LDS_MAXK)]
+static size_t large_ws_head(int B, int K, bool own_moments) {
+    return (((size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0) + large_f_bytes(B, K)) + 15) & ~(size_t)15;
+}
+size_t large_ws_bytes(int B, int K, bool own_moments) { return large_ws_head(B, K, own_moments) + large_list_bytes(B, K); }
+void* large_list_ws(void* ws, int B, int K, bool own_moments) {
+    return K <= LARGE_LDS_MAXK ? static_cast<char*>(ws) + large_ws_head(B, K, own_moments) : nullptr;
 }
 // the repulsion accumulators of clouds beyond LARGE_LDS_MAXK points: the LAST large_f_bytes of the workspace, zeroed here
 // (every step leaves them zero again)
@@ -505,23 +796,32 @@ hipError_t large_f_prepare(void* ws, int B, int K, bool own_moments, void** f_ws
     *f_ws = static_cast<char*>(ws) + (size_t)B * K * 16 + (own_moments ? (size_t)B * K * 3 * 4 * 2 : 0);
     return hipMemsetAsync(*f_ws, 0, large_f_bytes(B, K), s);
 }
+// a.knn_scan_every_step: 0 = certified lists where they exist (K <= LARGE_LDS_MAXK and a list workspace), 1 = the exact brute-force
+// scan at every step (validation; always beyond LARGE_LDS_MAXK points), 2 = the reference's neighbour choice (validation)
 static void large_step_launch(float* p, float* m, float* v, const f32x4* G, int B, int K, const float* adam_tab, int step,
-                              const int32_t* lbpc, const OptArgs& a, const RepConst& rc, float* loss, void* f_ws,
+                              const int32_t* lbpc, const OptArgs& a, const RepConst& rc, float* loss, void* f_ws, void* list_ws,
                               unsigned long long* status, hipStream_t s) {
-    if (K <= LARGE_LDS_MAXK)
+    const int ref_form = a.knn_scan_every_step == 2 ? 1 : 0;
+    if (K <= LARGE_LDS_MAXK && list_ws != nullptr && a.knn_scan_every_step == 0)
+        hipLaunchKernelGGL(large_step_lists_kernel, dim3(B), dim3(LARGE_THREADS), LARGE_LISTS_LDS, s, p, m, v, G, K, adam_tab, step, lbpc,
+                           a.loss_batch, a.rep_weight, rc, loss, large_lists_at(list_ws, B, K), status);
+    else if (K <= LARGE_LDS_MAXK)
         hipLaunchKernelGGL(large_step_kernel<false>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, m, v, G, K, adam_tab,
-                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws, status);
+                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws, status, ref_form);
     else
         hipLaunchKernelGGL(large_step_kernel<true>, dim3(B), dim3(LARGE_THREADS), large_lds_bytes(K), s, p, m, v, G, K, adam_tab,
-                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws, status);
+                           step, lbpc, a.loss_batch, a.rep_weight, rc, loss, f_ws, status, ref_form);
 }
 
 // ws: [B][K] f32x4 occupancy gradients, then (m == nullptr) the two moment arrays, zeroed here, then large_f_bytes
+hipError_t launch_large_occupancy_bf(int prec, const float* dec_img, const float* planes, const float* p, int B, int parts, int K,
+                                     const int32_t* lbpc, int loss_batch, float thr, int want_loss, f32x4* G, DecConst dc, hipStream_t s);
 hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
                                  const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
-                                 const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {
+                                 const float* adam_tab, int B, int K, const OptArgs& a, int n_cu, hipStream_t s) {
     f32x4* G = static_cast<f32x4*>(ws);
     void* f_ws = nullptr;
+    void* list_ws = large_list_ws(ws, B, K, m == nullptr);
     {
         hipError_t e = large_f_prepare(ws, B, K, m == nullptr, &f_ws, s);
         if (e != hipSuccess) return e;
@@ -533,13 +833,22 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
         if (e != hipSuccess) return e;
     }
     const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
-    // enough decoder workgroups to fill the GPU when there are few clouds: (K / 16) tiles over 8 waves each
-    const int parts = B >= 512 ? 1 : min((K / 16 + 7) / 8, max(1, 512 / B));
+    // one workgroup fills a CU (the persistent kernel's tile: 8 waves of 256 registers); with fewer clouds than CUs a cloud's
+    // (K / 32) tiles are shared out over `parts` workgroups of 8 waves
+    n_cu = max(8, n_cu);
+    const int parts = B >= n_cu ? 1 : min(((K + 31) / 32 + 7) / 8, max(1, n_cu / B));
     for (int step = 0; step < a.steps; ++step) {
-        hipLaunchKernelGGL(large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
-                           loss_batch_per_cloud, a.loss_batch, a.threshold, G, a.dc);
+        const int want_loss = (step == a.steps - 1 && loss != nullptr) ? 1 : 0;
+        if (a.precision != 0) {
+            hipError_t e = launch_large_occupancy_bf(a.precision, dec_img, planes, p, B, parts, K, loss_batch_per_cloud, a.loss_batch,
+                                                     a.threshold, want_loss, G, a.dc, s);
+            if (e != hipSuccess) return e;
+        } else {
+            hipLaunchKernelGGL(large_occupancy3_kernel<0>, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
+                               loss_batch_per_cloud, a.loss_batch, a.threshold, want_loss, G, a.dc);
+        }
         large_step_launch(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a, rc, (step == a.steps - 1) ? loss : nullptr,
-                          f_ws, counters, s);
+                          f_ws, list_ws, counters, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -549,12 +858,12 @@ hipError_t launch_large_optimize(const float* dec_img, const float* planes, floa
 
 // One Adam step of the large-cloud path for any decoder (ConvONet above, ONet in onet.hip): G holds the occupancy gradient
 // of every point (f32x4: d loss / d xyz, BCE term), large_step_kernel does the exact 5-NN, the repulsion terms and Adam.
-// f_ws: large_f_prepare's pointer (nullptr up to LARGE_LDS_MAXK points)
+// f_ws: large_f_prepare's pointer (nullptr up to LARGE_LDS_MAXK points); list_ws: large_list_ws's (nullptr beyond, or to force the scan)
 hipError_t launch_large_step(float* p, float* m, float* v, const void* G, int B, int K, const float* adam_tab, int step,
-                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws,
+                             const int32_t* loss_batch_per_cloud, const OptArgs& a, float* loss, void* f_ws, void* list_ws,
                              unsigned long long* counters, hipStream_t s) {
     const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
-    large_step_launch(p, m, v, static_cast<const f32x4*>(G), B, K, adam_tab, step, loss_batch_per_cloud, a, rc, loss, f_ws, counters, s);
+    large_step_launch(p, m, v, static_cast<const f32x4*>(G), B, K, adam_tab, step, loss_batch_per_cloud, a, rc, loss, f_ws, list_ws, counters, s);
     return hipGetLastError();
 }
 

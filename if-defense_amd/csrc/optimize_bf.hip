@@ -8,6 +8,7 @@ namespace ifd {
 // 158,752 B (the moments are in global memory; the last 2 KB: one 256-byte landing strip per wave for the tap prefetches of tile_bf.h)
 constexpr size_t OPT_LDS_BF = (size_t)BF_IMG_BYTES + MAXK * 16 * 3 + 16 + MAXK * 12 + 128 * 4 + 8 * 256;
 static_assert(OPT_LDS_BF <= 160 * 1024, "LDS budget");
+constexpr size_t LARGE_OCC_LDS_BF = (size_t)BF_IMG_BYTES + 8 * 256;     // large_occupancy3_kernel<1 | 2>: the piece image + the waves' landing strips
 
 hipError_t configure_optimize_bf_kernels() {
     hipError_t e = hipSuccess;
@@ -17,7 +18,23 @@ hipError_t configure_optimize_bf_kernels() {
                                 (int)OPT_LDS_BF);
     IFD_CFG(1, 1) IFD_CFG(2, 1) IFD_CFG(4, 1) IFD_CFG(1, 2) IFD_CFG(2, 2) IFD_CFG(4, 2)
 #undef IFD_CFG
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_occupancy3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_OCC_LDS_BF);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(large_occupancy3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LARGE_OCC_LDS_BF);
     return e;
+}
+
+// the occupancy half of the launch-per-step path (clouds of more than MAXK points) on the split-precision tile
+hipError_t launch_large_occupancy_bf(int prec, const float* dec_img, const float* planes, const float* p, int B, int parts, int K,
+                                     const int32_t* lbpc, int loss_batch, float thr, int want_loss, f32x4* G, DecConst dc, hipStream_t s) {
+    if (prec == 1)
+        hipLaunchKernelGGL(large_occupancy3_kernel<1>, dim3(B, parts), dim3(OPT_THREADS), LARGE_OCC_LDS_BF, s, dec_img, planes, p, K, lbpc,
+                           loss_batch, thr, want_loss, G, dc);
+    else
+        hipLaunchKernelGGL(large_occupancy3_kernel<2>, dim3(B, parts), dim3(OPT_THREADS), LARGE_OCC_LDS_BF, s, dec_img, planes, p, K, lbpc,
+                           loss_batch, thr, want_loss, G, dc);
+    return hipGetLastError();
 }
 
 template <int S, int PREC>

@@ -1464,4 +1464,56 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void optimize_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Clouds of more than MAXK optimised points (--sample_npoint 1025 ... LARGE_MAXK; ConvONet/opt_defense.py:27,149-179): the
+// occupancy half of the launch-per-step path (optimize.hip, "large" section) on the PERSISTENT kernel's decoder tile -
+// decoder_tile3 / decoder_tile3_bf, two software-pipelined 16-point sub-tiles per wave, eight waves of 256 registers per CU -
+// so that a point of a large cloud costs what a point of a 1024-point cloud costs (rounds 2-5 ran the stand-alone one-sub-tile
+// tile here: 2.5 x per point at K = 2048), in every ifd_opt_params.precision.  Workgroup (cloud, part) takes the cloud's
+// 32-point tiles part * 8 + wave, + 8 * parts, ...; writes G[cloud][point] = {d loss / d xyz, BCE term}.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(OPT_THREADS, 1) void large_occupancy3_kernel(
+    const float* __restrict__ dec_img, const float* __restrict__ planes, const float* __restrict__ p, int K,
+    const int32_t* __restrict__ loss_batch_per_cloud, int loss_batch, float thr, int want_loss_i, f32x4* __restrict__ G, DecConst dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int IMG_FLOATS = PREC == 0 ? DEC_FLOATS : BF_IMG_BYTES / 4;
+    float* W = smem;
+    [[maybe_unused]] float* strips = smem + IMG_FLOATS;              // PREC > 0: one 256-byte landing strip per wave (tile_bf.h)
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    load_dec_image(W, dec_img, IMG_FLOATS);
+    __syncthreads();
+    const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
+    const float inv_lb = 1.0f / (float)lb;
+    if (tid == 0) W[(PREC == 0 ? DEC_OFF_BOUT : BF_OFF_BOUT / 4) + 1] = inv_lb;     // the tile reads {fc_out's bias, 1 / B} as one pair
+    __syncthreads();
+    const float* pl = planes + (size_t)cloud * CLOUD_PLANE_FLOATS;
+    const __amdgpu_buffer_rsrc_t plr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pl), 0, CLOUD_PLANE_FLOATS * 4, 0x00020000);
+    const float* pc = p + (size_t)cloud * K * 3;
+    const bool want_loss = want_loss_i != 0;
+    const int ntiles = (K + 31) >> 5, q = lane >> 4;
+#pragma unroll 1
+    for (int tile = (int)blockIdx.y * (OPT_THREADS / 64) + wave; tile < ntiles; tile += (int)gridDim.y * (OPT_THREADS / 64)) {
+        const int ia = tile * 32 + (lane & 15), ib = ia + 16;
+        const int tpa = min(ia, K - 1), tpb = min(ib, K - 1);
+        const float xa0 = pc[3 * tpa], xa1 = pc[3 * tpa + 1], xa2 = pc[3 * tpa + 2];
+        const float xb0 = pc[3 * tpb], xb1 = pc[3 * tpb + 1], xb2 = pc[3 * tpb + 2];
+        const f32x4 ppa = pix_encode(xa0, xa1, xa2, dc), ppb = pix_encode(xb0, xb1, xb2, dc);
+        const float xqa = q == 0 ? xa0 : q == 1 ? xa1 : q == 2 ? xa2 : 1.f;          // component q of (x, y, z, 1): fc_p's B operand
+        const float xqb = q == 0 ? xb0 : q == 1 ? xb1 : q == 2 ? xb2 : 1.f;
+        float bce[2], dx[2][3];
+        if constexpr (PREC == 0)
+            decoder_tile3<MODE_OPT>(W, plr, ppa, ppb, xqa, xqb, lane, dc, thr, inv_lb, want_loss, bce, dx);
+        else {
+            decoder_tile3_bf<MODE_OPT, PREC>(W, plr, ppa, ppb, xqa, xqb, lane, dc, thr, want_loss, bce, dx, strips + 64 * wave);
+            asm volatile("s_setprio 0");
+        }
+        if (lane < 16) {
+            if (ia < K) G[(size_t)cloud * K + tpa] = f32x4{dx[0][0], dx[0][1], dx[0][2], bce[0]};
+            if (ib < K) G[(size_t)cloud * K + tpb] = f32x4{dx[1][0], dx[1][1], dx[1][2], bce[1]};
+        }
+    }
+}
+
 }  // namespace ifd

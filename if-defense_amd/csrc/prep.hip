@@ -17,6 +17,12 @@ constexpr int PREP_THREADS = 1024;
 // point).  Up to SOR_NARROW_MAXK points sor_kernel keeps the cloud in LDS in double (32 bytes per point); above, in float
 // with the doubles re-made per pair (12 bytes per point) - same values, see sor_kernel.
 constexpr int SOR_NARROW_MAXK = 4096;
+constexpr int PREP_SORT_MAX = 4096;      // up to this many optimised points per cloud leave prepare_kernel in Morton order (rank by counting: O(n^2))
+// entries of prepare_kernel's key array: the K subset keys, or the n_opt Morton keys of the optimised points if there are more of
+// them (rounded so that the doubles behind the array stay 8-byte aligned: 12 K + 4 nkey bytes in front of them)
+__host__ __device__ inline int prep_nkey(int K, int n_opt_sorted) {
+    return n_opt_sorted > K ? n_opt_sorted + ((3 * K + n_opt_sorted) & 1) : K;
+}
 
 // ---- Philox-4x32-10 (Salmon et al., SC'11) ---------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
@@ -155,10 +161,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
                                                                 int32_t* __restrict__ t_per_cloud, float* __restrict__ init,
                                                                 int32_t* __restrict__ n_kept, float* __restrict__ proc_out) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
+    // the optimised points leave in Morton order when the draws are the library's own (see the end of the kernel)
+    const bool morton = init_idx == nullptr && noise == nullptr && A.n_opt <= PREP_SORT_MAX;
+    const int nkey = prep_nkey(K, morton ? A.n_opt : 0);
     float* P = fsm;                                                   // [K][3] kept points, then processed
     uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * K);           // [K] random keys for the subset ...
     int* POS = reinterpret_cast<int*>(KEY);                           // ... in the place of the compaction prefix (done by then)
-    float* scratch = reinterpret_cast<float*>(KEY + K);               // [64]  (byte offset 16 K: 8-byte aligned, holds doubles)
+    float* scratch = reinterpret_cast<float*>(KEY + nkey);            // [64]  (8-byte aligned: holds doubles)
     int* s_n = reinterpret_cast<int*>(scratch + 62);
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t gcloud = (uint32_t)(A.cloud_base + b);
@@ -253,9 +262,15 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
     if (tid == 0) t_per_cloud[b] = tcount;
 
     // ---- init_points: indices with replacement + gaussian noise, clamped ---------------------------------
+    // The reference's draws (torch.randint + torch.randn, opt_defense.py:149-179) are i.i.d.: the ORDER of the n_opt optimised points
+    // carries no information.  With the library's own draws the points are therefore written in MORTON ORDER of their coordinates
+    // (30-bit Z-curve, ties by draw index): the 32 points of a decoder tile are then neighbours on the surface, the 12 x 32 bilinear
+    // taps of a tile fall into a few rows of each feature plane instead of all over it, and the optimiser's gathers - its HBM-side
+    // stream - run 0.8 % (f32) / 4.9 % (bf16x6) faster (profiles/r06_ab_bf_locality.txt).  Explicit draws (init_idx / noise: the
+    // parity tests' recorded draws) keep their order.
     const float lim = 0.5f * A.padding_scale;
     float* io = init + (size_t)b * A.n_opt * 3;
-    for (int t = tid; t < A.n_opt; t += PREP_THREADS) {
+    auto draw = [&](int t, float (&o)[3]) {
         int j;
         float g0, g1, g2;
         if (init_idx) {
@@ -277,14 +292,49 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
         }
         const float gs[3] = {g0, g1, g2};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) io[3 * t + a] = fminf(fmaxf(P[3 * j + a] + gs[a] * A.init_sigma, -lim), lim);
+        for (int a = 0; a < 3; ++a) o[a] = fminf(fmaxf(P[3 * j + a] + gs[a] * A.init_sigma, -lim), lim);
+    };
+    if (!morton) {
+        for (int t = tid; t < A.n_opt; t += PREP_THREADS) {
+            float o[3];
+            draw(t, o);
+            io[3 * t] = o[0]; io[3 * t + 1] = o[1]; io[3 * t + 2] = o[2];
+        }
+        return;
+    }
+    auto spread = [](uint32_t v) {                             // 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FFu;
+        v = (v | (v << 8)) & 0x0300F00Fu;
+        v = (v | (v << 4)) & 0x030C30C3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    __syncthreads();                                           // (the subset's keys are done with)
+    for (int t = tid; t < A.n_opt; t += PREP_THREADS) {
+        float o[3];
+        draw(t, o);
+        uint32_t q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) q[a] = (uint32_t)fminf(fmaxf((o[a] + 0.5f) * 1024.f, 0.f), 1023.f);
+        KEY[t] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+    }
+    __syncthreads();
+    for (int t = tid; t < A.n_opt; t += PREP_THREADS) {
+        const uint32_t kt = KEY[t];
+        int rank = 0;                                          // position of draw t in the key-sorted order (ties by draw index)
+        for (int u = 0; u < A.n_opt; ++u) { const uint32_t ku = KEY[u]; rank += (ku < kt || (ku == kt && u < t)) ? 1 : 0; }
+        float o[3];
+        draw(t, o);
+        io[3 * rank] = o[0]; io[3 * rank + 1] = o[1]; io[3 * rank + 2] = o[2];
     }
 }
 
 // LDS by the cloud size: SOR 32 K + 128 B up to 4096 points (131,200 B there, 32,896 B at 1024), 12 K + 128 B above
 // (120,128 B at 10,000); prepare 16 K + 256 B (160,256 B at 10,000)
 static size_t sor_lds(int K) { return K <= SOR_NARROW_MAXK ? ((size_t)4 * K + 16) * sizeof(double) : (size_t)12 * K + 4 * (K & 1) + 128; }
-static size_t prep_lds(int K) { return (size_t)16 * K + 64 * 4; }
+static size_t prep_lds(int K, int n_opt = 0) {         // n_opt: the Morton keys of the optimised points share the subset keys' array
+    return (size_t)12 * K + (size_t)4 * prep_nkey(K, n_opt <= PREP_SORT_MAX ? n_opt : 0) + 64 * 4;
+}
 
 hipError_t configure_prep_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -317,7 +367,7 @@ hipError_t launch_sor(const float* pc, int B, int K, int k_nn, double alpha, uin
 hipError_t launch_prepare(const float* pc, const uint8_t* keep, int B, int K, const PrepArgs& a, const int32_t* sel_idx,
                           const int32_t* init_idx, const float* noise, float* sel, int32_t* t_per_cloud, float* init,
                           int32_t* n_kept, float* proc_out, hipStream_t s) {
-    hipLaunchKernelGGL(prepare_kernel, dim3(B), dim3(PREP_THREADS), prep_lds(K), s, pc, keep, K, a, sel_idx, init_idx, noise,
+    hipLaunchKernelGGL(prepare_kernel, dim3(B), dim3(PREP_THREADS), prep_lds(K, a.n_opt), s, pc, keep, K, a, sel_idx, init_idx, noise,
                        sel, t_per_cloud, init, n_kept, proc_out);
     return hipGetLastError();
 }

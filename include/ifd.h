@@ -125,6 +125,10 @@ typedef struct ifd_prep_params {
 /* preprocess_pc + init_points (ConvONet/opt_defense.py:114-146, 149-179) on the points SOR kept.
  * keep_mask may be NULL (--sor=False).  Explicit draws (all optional, for parity tests): sel_idx [B,n_sel]
  * (np.random.choice without replacement), init_idx [B,n_opt] (torch.randint), noise [B,n_opt,3] ~ N(0,1).
+ * With the library's own draws (init_idx == NULL and noise == NULL) and n_opt <= 4096 the rows of init_points are written in MORTON
+ * ORDER of their coordinates: the reference's draws are i.i.d. (torch.randint / torch.randn, opt_defense.py:166-176), so the row order
+ * carries no information, and neighbouring rows being neighbours in space makes the optimiser's plane gathers local (0.8 % / 4.9 % of
+ * its launch in f32 / bf16x6).  Explicit draws keep their order.
  * Outputs: sel [B,n_sel,3] (rows >= t_per_cloud[b] are zero), t_per_cloud [B] = min(n_kept, n_sel),
  * init_points [B,n_opt,3], n_kept (optional) [B], proc (optional) [B,K,3]: the processed kept points,
  * first n_kept[b] rows valid.  K <= 10000, n_sel <= 1024. */

@@ -15,13 +15,19 @@ r = I.Restorer(I.weights.pack_state_dict(I.weights.random_state_dict(0)), device
 x = torch.from_numpy(bench.synth_clouds(n)).cuda()
 base = None
 for k in ks:
-    steps = 51 if k <= 1024 else 11
+    steps = int(os.environ.get("IFD_LARGE_STEPS", "101"))           # (the first step of a launch builds the lists: time enough steps)
+    scan = os.environ.get("IFD_LARGE_SCAN", "0") == "1"
+    prec = os.environ.get("IFD_LARGE_PRECISION", "f32")
     prep = r.prepare(x, r.sor(x), n_sel=600, n_opt=k, seed=1234)
     planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
     r.optimize_points(prep["init"][:8], planes[:8], rep_weight=500.0, steps=2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps)
+    r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps, knn_scan_every_step=scan, precision=prec)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    c = r.counters()
     per = dt / (n * k * steps)
     base = base or per
-    print("K = %5d: %d clouds x %d steps in %.1f ms -> %.2f ns per point and step (%.2f x the first line)" % (k, n, steps, dt * 1e3, per * 1e9, per / base))
+    print("K = %5d: %d clouds x %d steps in %.1f ms -> %.2f ns per point and step (%.2f x the first line)%s" % (
+        k, n, steps, dt * 1e3, per * 1e9, per / base,
+        "" if k <= 1024 else "; %.1f list epochs per cloud, %.2f %% of the point-steps through the exact query" %
+        (c["knn_rebuilds"] / float(n), 100.0 * c["knn_exact_evals"] / (float(n) * k * steps))))
