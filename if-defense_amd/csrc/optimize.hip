@@ -256,10 +256,10 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
 // (distance bits | index) through the sorted top-6 network of knn_device.h - the five smallest keys are the five nearest list members
 // unless keys 5 and 6 tie above the index bits.
 //   * certificate holds, no tie: the five neighbours are the exact 5-NN; repulsion terms at once (rep_point2);
-//   * otherwise the point goes to an LDS queue; after a barrier the workgroup's 16 waves take the queued points one at a time: the
-//     lanes split the K candidates, per-lane sorted top-5, five rounds of a wave-wide (distance, index) minimum = the exact 5-NN in
-//     the scan's own order, then the point's list is rebuilt around it (rho^2 = 5 d5^2; 2.5 d5^2 if that ball overflows the list; a
-//     ball that still overflows leaves rho = 0: that point is resolved exactly every step) and its terms are added;
+//   * otherwise the point goes to an LDS queue; after a barrier the queued points are shared out FOUR LANES each: one pass over the K
+//     candidates gives the exact 5-NN in the scan's own order (per-lane sorted top-5, merged by (distance, index)) and writes the point's
+//     new list (radius^2 = the point's own alpha x the failed list's upper bound of d5^2; the nearest hit that did not fit caps the
+//     certified radius; a useless list is collected once more around the exact d5), then its terms are added;
 //   * the first step of a call: every thread runs the exact scan for its points (knn_scan2: the brute-force kernel's code) and builds
 //     their lists itself.  There is NO later whole-cloud rebuild: the step is one launch for all clouds, so a rebuild of any one cloud
 //     would set the duration of that step for all of them (measured: epochs every ~7 steps per cloud made EVERY step an epoch step,
@@ -267,47 +267,37 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_kernel(float* __rest
 // Every path selects the five smallest (distance, index) pairs and the repulsion sums are fixed point: outputs are bit-identical to
 // large_step_kernel's (ifd_opt_params.knn_scan_every_step selects that kernel; tests/test_gpu_parity.py holds the two against each other).
 // ---------------------------------------------------------------------------------------------
-constexpr int LL_M = 32;                            // list entries per point
+constexpr int LL_M = 64;                            // list entries per point (128 bytes)
 constexpr unsigned int LL_IDX_MASK = 8191u;         // 13 index bits: 0 ... LARGE_LDS_MAXK (the dummy entry)
 constexpr int LL_DUMMY = LARGE_LDS_MAXK;            // X[LL_DUMMY]: a far-away point (unused list slots)
-constexpr float LL_ALPHA = 5.f;                     // rho^2 = LL_ALPHA d5^2: ~25 of the 32 entries on a surface, slack rho - r5 = 1.24 r5
+constexpr float LL_ALPHA = 6.4f;                    // first rho^2 = LL_ALPHA d5^2: ~32 of the 64 entries on a surface, slack rho - r5 = 1.5 r5
+constexpr int LL_Q = LL_M / 4;                      // a renewed list is written by four lanes, a quarter each
 struct LargeLists {
     uint16_t* lists;     // [B][K][LL_M]
     f32x4* cert;         // [B][K]  {position at build time, rho}
-    float* dbase;        // [B][K]  S at build time
+    f32x2* dbase;        // [B][K]  {S at build time, alpha: the point's own rho^2 / d5^2 - shrunk when its ball overflowed its list, grown when it
+                         //          was half empty, like the persistent kernel's al_f / al_b}
     float* scal;         // [B][4]  S(now) = sum over the call's steps so far of max_j |x_j(s + 1) - x_j(s)|, -, -, -
 };
 size_t large_list_bytes(int B, int K) {
-    return K <= LARGE_LDS_MAXK ? (size_t)B * K * (LL_M * 2 + 16 + 4) + (size_t)B * 16 : 0;
+    return K <= LARGE_LDS_MAXK ? (size_t)B * K * (LL_M * 2 + 16 + 8) + (size_t)B * 16 : 0;
 }
 static LargeLists large_lists_at(void* base, int B, int K) {
     LargeLists L;
     char* c = static_cast<char*>(base);
     L.cert = reinterpret_cast<f32x4*>(c);                       c += (size_t)B * K * 16;
     L.lists = reinterpret_cast<uint16_t*>(c);                   c += (size_t)B * K * LL_M * 2;
-    L.dbase = reinterpret_cast<float*>(c);                      c += (size_t)B * K * 4;
+    L.dbase = reinterpret_cast<f32x2*>(c);                      c += (size_t)B * K * 8;
     L.scal = reinterpret_cast<float*>(c);
     return L;
 }
-constexpr size_t LARGE_LISTS_LDS = (size_t)(LARGE_LDS_MAXK + 1) * 16 + (size_t)LARGE_LDS_MAXK * (8 + 4 + 4 + 2) + 64 * 4 + 16;   // 139,552 B
+constexpr size_t LARGE_LISTS_LDS = (size_t)(LARGE_LDS_MAXK + 1) * 16 + (size_t)LARGE_LDS_MAXK * (8 + 4 + 4 + 2 + 4) + 64 * 4 + 16;   // 155,936 B
 
 __device__ __forceinline__ float ll_dist2(const f32x4& a, const f32x4& b) {
     const float ex = a.x - b.x, ey = a.y - b.y, ez = a.z - b.z;
     return fmaf(ez, ez, fmaf(ey, ey, ex * ex));                  // knn_scan2's expression
 }
-// inclusive prefix sum over the wave (DPP inside the rows of 16, the row totals through readlane: knn_build_one's scheme)
-__device__ __forceinline__ int ll_wave_scan(int v, int lane, int& total) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
-    const int r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
-    const int row = lane >> 4;
-    total = r0 + r1 + r2 + r3;
-    return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
-}
-// one thread builds the list of its point i (first step): every j != i with |x_j - x_i|^2 < r2, r2 = 5 d5^2, or 2.5 d5^2 if that ball
+// one thread builds the list of its point i: every j != i with |x_j - x_i|^2 < r2, r2 = LL_ALPHA d5^2, or half that if that ball
 // holds more than LL_M points; returns rho (0: no valid list)
 __device__ __forceinline__ float ll_build_thread(const f32x4* __restrict__ X, int K, int i, float d5sq, uint16_t* __restrict__ lst) {
     const f32x4 xi = X[i];
@@ -332,43 +322,47 @@ __device__ __forceinline__ float ll_build_thread(const f32x4* __restrict__ X, in
     }
     return rho;
 }
-// keys of the two points' lists (list_keys6_2 with 13 index bits and LL_M entries)
+// keys of the two points' lists (list_keys6_2 with 13 index bits and LL_M entries; the index words in two halves: 128 registers)
 __device__ __forceinline__ void ll_keys2(const f32x4* __restrict__ X, const uint16_t* __restrict__ La, const uint16_t* __restrict__ Lb,
                                          int ia, int ib, Keys6& qa, Keys6& qb) {
     const f32x4 xa = X[ia], xb = X[ib];
-    u32x4 wa[LL_M / 8], wb[LL_M / 8];
 #pragma unroll
-    for (int c = 0; c < LL_M / 8; ++c) {
-        wa[c] = reinterpret_cast<const u32x4*>(La)[c];
-        wb[c] = reinterpret_cast<const u32x4*>(Lb)[c];
-    }
+    for (int half = 0; half < 2; ++half) {
+        u32x4 wa[LL_M / 16], wb[LL_M / 16];
 #pragma unroll
-    for (int c = 0; c < LL_M / 4; ++c) {                                                  // four entries of each list at a time
-        unsigned int ja[4], jb[4];
-        f32x4 pa_[4], pb_[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned int pka = wa[c >> 1][2 * (c & 1) + (e >> 1)], pkb = wb[c >> 1][2 * (c & 1) + (e >> 1)];
-            ja[e] = (e & 1) ? (pka >> 16) : (pka & 0xffffu);
-            jb[e] = (e & 1) ? (pkb >> 16) : (pkb & 0xffffu);
+        for (int c = 0; c < LL_M / 16; ++c) {
+            wa[c] = reinterpret_cast<const u32x4*>(La)[half * (LL_M / 16) + c];
+            wb[c] = reinterpret_cast<const u32x4*>(Lb)[half * (LL_M / 16) + c];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pa_[e] = X[ja[e]]; pb_[e] = X[jb[e]]; }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < LL_M / 8; ++c) {                                              // four entries of each list at a time
+            unsigned int ja[4], jb[4];
+            f32x4 pa_[4], pb_[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            keys6_insert(qa, (__float_as_uint(ll_dist2(pa_[e], xa)) & ~LL_IDX_MASK) | ja[e]);
-            keys6_insert(qb, (__float_as_uint(ll_dist2(pb_[e], xb)) & ~LL_IDX_MASK) | jb[e]);
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int pka = wa[c >> 1][2 * (c & 1) + (e >> 1)], pkb = wb[c >> 1][2 * (c & 1) + (e >> 1)];
+                ja[e] = (e & 1) ? (pka >> 16) : (pka & 0xffffu);
+                jb[e] = (e & 1) ? (pkb >> 16) : (pkb & 0xffffu);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pa_[e] = X[ja[e]]; pb_[e] = X[jb[e]]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                keys6_insert(qa, (__float_as_uint(ll_dist2(pa_[e], xa)) & ~LL_IDX_MASK) | ja[e]);
+                keys6_insert(qb, (__float_as_uint(ll_dist2(pb_[e], xb)) & ~LL_IDX_MASK) | jb[e]);
+            }
         }
     }
 }
 // the five smallest keys as neighbour indices + whether they are certified to be the exact 5-NN of the point
-__device__ __forceinline__ bool ll_certify(const Keys6& q, const f32x4& x, const f32x4& cert, float dsum, Top5& t) {
+__device__ __forceinline__ bool ll_certify(const Keys6& q, const f32x4& x, const f32x4& cert, float dsum, Top5& t, float& d5ub) {
     t.i0 = (int)(q.k0 & LL_IDX_MASK); t.i1 = (int)(q.k1 & LL_IDX_MASK); t.i2 = (int)(q.k2 & LL_IDX_MASK);
     t.i3 = (int)(q.k3 & LL_IDX_MASK); t.i4 = (int)(q.k4 & LL_IDX_MASK);
     t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = 0.f;
     const bool tie = ((q.k4 ^ q.k5) & ~LL_IDX_MASK) == 0u;
-    const float r5 = q.k4 >= 0x7f800000u ? INFINITY : sqrtf(__uint_as_float(q.k4 | LL_IDX_MASK));     // upper bound of the 5th distance
+    d5ub = q.k4 >= 0x7f800000u ? INFINITY : __uint_as_float(q.k4 | LL_IDX_MASK);       // upper bound of the squared 5th distance:
+    const float r5 = sqrtf(d5ub);                                                       // the list's 5th nearest is no nearer than the true one
     const float ex = x.x - cert.x, ey = x.y - cert.y, ez = x.z - cert.z;
     const float moved = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
     // (strict, with room for the roundings of the three square roots and of D: all O(1e-7) relative)
@@ -390,7 +384,8 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
     float* RL = reinterpret_cast<float*>(Fz.z + LARGE_LDS_MAXK);                      // [LARGE_LDS_MAXK] repulsion loss term of every point
     float* scratch = RL + LARGE_LDS_MAXK;                                             // [64]
     int* qn = reinterpret_cast<int*>(scratch + 64);                                   // queue length (+ 3 pad)
-    uint16_t* queue = reinterpret_cast<uint16_t*>(qn + 4);                            // [LARGE_LDS_MAXK]
+    float* qd5 = reinterpret_cast<float*>(qn + 4);                                    // [LARGE_LDS_MAXK] upper bound of the queued point's squared 5th distance
+    uint16_t* queue = reinterpret_cast<uint16_t*>(qd5 + LARGE_LDS_MAXK);              // [LARGE_LDS_MAXK]
     const size_t cb = (size_t)cloud * K;
     float* pc = p + cb * 3;
     constexpr int PPT = LARGE_LDS_MAXK / LARGE_THREADS;                               // 4 points per thread
@@ -419,23 +414,24 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
                     const float rho = ll_build_thread(X, K, pa, ta.d4, L.lists + (cb + pa) * LL_M);
                     const f32x4 x = X[pa];
                     L.cert[cb + pa] = f32x4{x.x, x.y, x.z, rho};
-                    L.dbase[cb + pa] = 0.f;
+                    L.dbase[cb + pa] = f32x2{0.f, LL_ALPHA};
                 }
                 if (vb) {
                     const float rho = ll_build_thread(X, K, pb, tb.d4, L.lists + (cb + pb) * LL_M);
                     const f32x4 x = X[pb];
                     L.cert[cb + pb] = f32x4{x.x, x.y, x.z, rho};
-                    L.dbase[cb + pb] = 0.f;
+                    L.dbase[cb + pb] = f32x2{0.f, LL_ALPHA};
                 }
             } else {
                 Keys6 qa, qb;
                 keys6_init(qa);
                 keys6_init(qb);
                 ll_keys2(X, L.lists + (cb + ia) * LL_M, L.lists + (cb + ib) * LL_M, ia, ib, qa, qb);
-                oka = va && ll_certify(qa, X[ia], L.cert[cb + ia], (d_now - L.dbase[cb + ia]) * 1.00001f, ta);
-                okb = vb && ll_certify(qb, X[ib], L.cert[cb + ib], (d_now - L.dbase[cb + ib]) * 1.00001f, tb);
-                if (va && !oka) queue[atomicAdd(qn, 1)] = (uint16_t)pa;
-                if (vb && !okb) queue[atomicAdd(qn, 1)] = (uint16_t)pb;
+                float ua, ub;
+                oka = va && ll_certify(qa, X[ia], L.cert[cb + ia], (d_now - L.dbase[cb + ia].x) * 1.00001f, ta, ua);
+                okb = vb && ll_certify(qb, X[ib], L.cert[cb + ib], (d_now - L.dbase[cb + ib].x) * 1.00001f, tb, ub);
+                if (va && !oka) { const int at = atomicAdd(qn, 1); queue[at] = (uint16_t)pa; qd5[at] = ua; }
+                if (vb && !okb) { const int at = atomicAdd(qn, 1); queue[at] = (uint16_t)pb; qd5[at] = ub; }
             }
             float la, lb;
             rep_point2(X, Fz, K, oka ? pa : K, okb ? pb : K, ta, tb, rc, la, lb);
@@ -443,59 +439,82 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
             if (okb) RL[pb] = lb;
         }
         __syncthreads();
-        // ---- the queued points: exact 5-NN by the whole wave, list rebuilt, terms added ------------------------------------
+        // ---- the queued points: FOUR LANES each (16 points side by side in a wave).  Measured on the way (profiles/r06_time_large_k*):
+        //      one point per WAVE with cross-lane minima costs 3 x the brute-force kernel's thread-level scan per point; one point per
+        //      THREAD leaves 2 - 3 lone, latency-bound waves walking all K candidates while 13 idle (0.88 ms per step at K = 2048, more
+        //      than the brute-force kernel's 0.66).  Lane s of a quad walks the candidates j = s (mod 4) ONCE: it keeps its own exact
+        //      sorted top-5 (knn_scan2's insertion, ascending index) and writes the candidates inside the new ball - radius^2 = the
+        //      point's alpha x the failed list's own upper bound of d5^2 - into ITS quarter of the list; a hit that finds its quarter
+        //      full is dropped and caps the certified radius at its distance (every point nearer than the nearest dropped hit is in the
+        //      list).  The four top-5 are merged by (distance, index) through DPP, so every lane ends with the scan's exact answer.
+        //      A list that came out useless (no bound to start from, or rho <= r5) is collected once more around the exact d5. -------
         const int nq = *qn;
+        const int sub = lane & 3;
 #pragma unroll 1
-        for (int qi = wave; qi < nq; qi += LARGE_THREADS / 64) {
-            const int i = queue[qi];
+        for (int base = 0; base < nq; base += LARGE_THREADS / 4) {                      // (block-uniform trip count)
+            const int qi = base + (tid >> 2);
+            const bool act = qi < nq;                                                   // quad-uniform
+            const int i = act ? (int)queue[qi] : 0;
             const f32x4 xi = X[i];
+            uint16_t* lst = L.lists + (cb + i) * LL_M + sub * LL_Q;
+            float alpha = act ? L.dbase[cb + i].y : LL_ALPHA;
+            float r2 = act ? alpha * qd5[min(qi, LARGE_LDS_MAXK - 1)] : 0.f;
+            if (!(r2 < 1e30f)) r2 = 0.f;                                               // (no usable bound: the second pass sets the radius)
             Top5 t;
-            top5_init(t);
-#pragma unroll 4
-            for (int j = lane; j < K; j += 64) {
-                const float d = j == i ? INFINITY : ll_dist2(X[j], xi);
-                top5_insert(t, d, j);                                                   // ascending j: ties keep the smaller index
-            }
-            Top5 res;
-            float rd[5];
-            int rj[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                float bd = t.d0;
-                int bj = t.d0 < INFINITY ? t.i0 : 0x7fffffff;
-                lexmin_wave(bd, bj);
-                rd[k] = bd;
-                rj[k] = bj;
-                if (bd < INFINITY && (bj & 63) == lane) {                               // the winner's lane pops its head
-                    t.d0 = t.d1; t.i0 = t.i1; t.d1 = t.d2; t.i1 = t.i2; t.d2 = t.d3; t.i2 = t.i3; t.d3 = t.d4; t.i3 = t.i4;
-                    t.d4 = INFINITY; t.i4 = 0;
-                }
-            }
-            res.d0 = rd[0]; res.d1 = rd[1]; res.d2 = rd[2]; res.d3 = rd[3]; res.d4 = rd[4];
-            res.i0 = rj[0]; res.i1 = rj[1]; res.i2 = rj[2]; res.i3 = rj[3]; res.i4 = rj[4];
-            // the point's new list
-            uint16_t* lst = L.lists + (cb + i) * LL_M;
-            float rho = 0.f;
+            float cap2 = 0.f;
+            int total = 0;
 #pragma unroll 1
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                const float r2 = (attempt == 0 ? LL_ALPHA : 0.5f * LL_ALPHA) * rd[4];
+            for (int pass = 0; pass < 2; ++pass) {
+                top5_init(t);
                 int cnt = 0;
-                for (int j = lane; j < K; j += 64) cnt += (j != i && ll_dist2(X[j], xi) < r2) ? 1 : 0;
-                int total;
-                const int incl = ll_wave_scan(cnt, lane, total);
-                if (total > LL_M) continue;                                             // wave-uniform
-                int at = incl - cnt;
-                for (int j = lane; j < K; j += 64)
-                    if (j != i && ll_dist2(X[j], xi) < r2) lst[at++] = (uint16_t)j;
-                if (lane >= total && lane < LL_M) lst[lane] = (uint16_t)LL_DUMMY;
-                rho = sqrtf(r2);
-                break;
+                float drop = INFINITY;
+#pragma unroll 4
+                for (int j = sub; j < K; j += 4) {
+                    const float d = j == i ? INFINITY : ll_dist2(X[j], xi);
+                    top5_insert(t, d, j);                                               // ascending j within the lane: ties keep the smaller index
+                    if (d < r2) {                                                       // (r2 = 0 for the quads without a point)
+                        if (cnt < LL_Q) lst[cnt] = (uint16_t)j; else drop = fminf(drop, d);
+                        ++cnt;
+                    }
+                }
+                if (act)
+                    for (int e = min(cnt, LL_Q); e < LL_Q; ++e) lst[e] = (uint16_t)LL_DUMMY;
+                // merge the quad's four sorted top-5 (the other lanes' ORIGINAL entries, by rotation inside the quad)
+                const Top5 o = t;
+#define IFD_LL_MERGE(CTRL)                                                                                                         \
+                {                                                                                                                  \
+                    const float od[5] = {o.d0, o.d1, o.d2, o.d3, o.d4};                                                            \
+                    const int oi[5] = {o.i0, o.i1, o.i2, o.i3, o.i4};                                                              \
+                    _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                                \
+                        const float dd = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(od[k]), CTRL, 0xf, 0xf, false)); \
+                        const int jj = __builtin_amdgcn_update_dpp(0, oi[k], CTRL, 0xf, 0xf, false);                               \
+                        if (dd < t.d4 || (dd == t.d4 && jj < t.i4)) top5_insert_lex(t, dd, jj);                                    \
+                    }                                                                                                              \
+                }
+                IFD_LL_MERGE(0x39)        // quad_perm [1, 2, 3, 0]
+                IFD_LL_MERGE(0x4E)        // quad_perm [2, 3, 0, 1]
+                IFD_LL_MERGE(0x93)        // quad_perm [3, 0, 1, 2]
+#undef IFD_LL_MERGE
+                // the quad's nearest dropped hit and its hit count
+                drop = fminf(drop, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(drop), 0xB1, 0xf, 0xf, false)));   // [1, 0, 3, 2]
+                drop = fminf(drop, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(drop), 0x4E, 0xf, 0xf, false)));   // [2, 3, 0, 1]
+                total = cnt;
+                total += __builtin_amdgcn_update_dpp(0, total, 0xB1, 0xf, 0xf, false);
+                total += __builtin_amdgcn_update_dpp(0, total, 0x4E, 0xf, 0xf, false);
+                cap2 = fminf(r2, drop);                                                 // everything nearer than this is in the list
+                if (drop < INFINITY) alpha *= 0.8f;                                    // the ball was too crowded for a quarter: smaller next time
+                else if (total < LL_M / 3) alpha *= 1.15f;                             // ... or mostly empty: larger
+                alpha = fminf(fmaxf(alpha, 1.5f), 16.f);
+                const bool again = act && pass == 0 && !(cap2 > t.d4);                 // useless list (quad-uniform): once more, around the exact d5
+                if (__ballot(again) == 0ull) break;                                     // (wave-uniform exit)
+                r2 = again ? alpha * t.d4 : 0.f;                                        // (the quads that are done collect nothing: their list stands)
+                if (!again) break;
             }
-            if (lane == 0) {
-                L.cert[cb + i] = f32x4{xi.x, xi.y, xi.z, rho};
-                L.dbase[cb + i] = d_now;
+            if (act && sub == 0) {
+                L.cert[cb + i] = f32x4{xi.x, xi.y, xi.z, cap2 > t.d4 ? sqrtf(cap2) : 0.f};
+                L.dbase[cb + i] = f32x2{d_now, alpha};
                 float la, lb;
-                rep_point2(X, Fz, K, i, K, res, res, rc, la, lb);
+                rep_point2(X, Fz, K, i, K, t, t, rc, la, lb);
                 RL[i] = la;
             }
         }
