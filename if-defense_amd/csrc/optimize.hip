@@ -396,6 +396,14 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
         Fz.xy[pt] = 0; Fz.z[pt] = 0; RL[pt] = 0.f;
     }
     if (tid == 0) { *qn = 0; X[LL_DUMMY] = f32x4{1e18f, 1e18f, 1e18f, 0.f}; }
+#ifdef IFD_PROF
+    // -DIFD_PROF (scripts/build_variant.sh prof): cycles of cloud 0's phases summed over the call into the counter slots 8 ... 12
+    unsigned long long pt_[6];
+#define LL_STAMP(k) do { __syncthreads(); pt_[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LL_STAMP(k)
+#endif
+    LL_STAMP(0);
     const bool epoch = step == 0;                                                     // the call's first step: every list is built
     const float d_now = epoch ? 0.f : L.scal[4 * cloud + 0];                          // S(now)
     __syncthreads();
@@ -439,6 +447,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
             if (okb) RL[pb] = lb;
         }
         __syncthreads();
+        LL_STAMP(1);
         // ---- the queued points: FOUR LANES each (16 points side by side in a wave).  Measured on the way (profiles/r06_time_large_k*):
         //      one point per WAVE with cross-lane minima costs 3 x the brute-force kernel's thread-level scan per point; one point per
         //      THREAD leaves 2 - 3 lone, latency-bound waves walking all K candidates while 13 idle (0.88 ms per step at K = 2048, more
@@ -454,29 +463,55 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
         for (int base = 0; base < nq; base += LARGE_THREADS / 4) {                      // (block-uniform trip count)
             const int qi = base + (tid >> 2);
             const bool act = qi < nq;                                                   // quad-uniform
+            if (__ballot(act) == 0ull) break;                                           // (no barrier in this loop: a wave without a point leaves)
             const int i = act ? (int)queue[qi] : 0;
             const f32x4 xi = X[i];
             uint16_t* lst = L.lists + (cb + i) * LL_M + sub * LL_Q;
             float alpha = act ? L.dbase[cb + i].y : LL_ALPHA;
-            float r2 = act ? alpha * qd5[min(qi, LARGE_LDS_MAXK - 1)] : 0.f;
-            if (!(r2 < 1e30f)) r2 = 0.f;                                               // (no usable bound: the second pass sets the radius)
+            // d5 <= tins: only candidates this near can be among the five nearest - the sorted insertion (~30 vector instructions, and a
+            // wave runs it whenever ONE of its 64 lanes needs it) is kept off the other ~2000 (measured: 486 -> see r06_time_large_k*)
+            float tins = act ? qd5[min(qi, LARGE_LDS_MAXK - 1)] : 0.f;
+            float r2 = alpha * tins;
+            if (!(r2 < 1e30f)) { r2 = 0.f; tins = INFINITY; }                          // (no usable bound: the second pass sets the radius)
             Top5 t;
             float cap2 = 0.f;
             int total = 0;
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
+#ifdef IFD_PROF
+                const unsigned long long q0_ = __builtin_readcyclecounter();
+#endif
                 top5_init(t);
                 int cnt = 0;
                 float drop = INFINITY;
-#pragma unroll 4
-                for (int j = sub; j < K; j += 4) {
-                    const float d = j == i ? INFINITY : ll_dist2(X[j], xi);
-                    top5_insert(t, d, j);                                               // ascending j within the lane: ties keep the smaller index
-                    if (d < r2) {                                                       // (r2 = 0 for the quads without a point)
-                        if (cnt < LL_Q) lst[cnt] = (uint16_t)j; else drop = fminf(drop, d);
-                        ++cnt;
+                // Branch-free over the candidates: 32 of the lane's candidates (j = w0 + 4 b + s) at a time, one bit each for "inside the
+                // ball or possibly among the five nearest"; the few set bits are then handled one by one, in ascending j.  (With a
+                // test-and-branch per candidate a wave ran the hit path whenever ONE of its 64 lanes had a hit - two iterations in three -
+                // and the sorted insertion likewise: 345 - 486 cycles per candidate and wave, measured.)
+                const float lim = fmaxf(r2, tins);                                     // (tins = INF without a bound: every candidate is looked at)
+#pragma unroll 1
+                for (int w0 = 0; w0 < K; w0 += 128) {
+                    unsigned int hit = 0u;
+#pragma unroll 8
+                    for (int bb = 0; bb < 32; ++bb) {
+                        const float d = ll_dist2(X[min(w0 + 4 * bb + sub, LL_DUMMY)], xi);      // (beyond K: masked below)
+                        hit |= (d <= lim ? 1u : 0u) << bb;
+                    }
+                    while (hit != 0u) {
+                        const int j = w0 + 4 * __builtin_ctz(hit) + sub;
+                        hit &= hit - 1u;
+                        if (j >= K || j == i) continue;
+                        const float d = ll_dist2(X[j], xi);
+                        if (d <= tins) top5_insert(t, d, j);                            // ascending j within the lane: ties keep the smaller index
+                        if (d < r2) {                                                   // (r2 = 0 for the quads without a point)
+                            if (cnt < LL_Q) lst[cnt] = (uint16_t)j; else drop = fminf(drop, d);
+                            ++cnt;
+                        }
                     }
                 }
+#ifdef IFD_PROF
+                const unsigned long long q1_ = __builtin_readcyclecounter();
+#endif
                 if (act)
                     for (int e = min(cnt, LL_Q); e < LL_Q; ++e) lst[e] = (uint16_t)LL_DUMMY;
                 // merge the quad's four sorted top-5 (the other lanes' ORIGINAL entries, by rotation inside the quad)
@@ -501,6 +536,14 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
                 total = cnt;
                 total += __builtin_amdgcn_update_dpp(0, total, 0xB1, 0xf, 0xf, false);
                 total += __builtin_amdgcn_update_dpp(0, total, 0x4E, 0xf, 0xf, false);
+#ifdef IFD_PROF
+                if (tid == 0 && cloud == 0 && status != nullptr) {
+                    const unsigned long long q2_ = __builtin_readcyclecounter();
+                    atomicAdd(status + 12, q1_ - q0_);          // candidate loop
+                    atomicAdd(status + 13, q2_ - q1_);          // fill + merge
+                    atomicAdd(status + 14, 1ull);               // passes of wave 0
+                }
+#endif
                 cap2 = fminf(r2, drop);                                                 // everything nearer than this is in the list
                 if (drop < INFINITY) alpha *= 0.8f;                                    // the ball was too crowded for a quarter: smaller next time
                 else if (total < LL_M / 3) alpha *= 1.15f;                             // ... or mostly empty: larger
@@ -508,6 +551,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
                 const bool again = act && pass == 0 && !(cap2 > t.d4);                 // useless list (quad-uniform): once more, around the exact d5
                 if (__ballot(again) == 0ull) break;                                     // (wave-uniform exit)
                 r2 = again ? alpha * t.d4 : 0.f;                                        // (the quads that are done collect nothing: their list stands)
+                tins = t.d4;                                                            // (exact now)
                 if (!again) break;
             }
             if (act && sub == 0) {
@@ -519,6 +563,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
             }
         }
         __syncthreads();
+        LL_STAMP(2);
         if (tid == 0 && status != nullptr) {                                            // diagnostics (ifd_get_counters)
             if (epoch) atomicAdd(status + 0, 1ull);                                     // (whole-cloud list builds: one per cloud and call)
             if (nq > 0) atomicAdd(status + 5, (unsigned long long)nq);
@@ -565,6 +610,16 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
         rep = block_sum(rep, scratch);
         if (tid == 0) { loss_out[2 * cloud] = occ; loss_out[2 * cloud + 1] = rep / ((float)K * 5.f); }
     }
+#ifdef IFD_PROF
+    LL_STAMP(3);
+    if (tid == 0 && cloud == 0 && status != nullptr && rep_weight > 0.f && !epoch) {
+        atomicAdd(status + 8, pt_[1] - pt_[0]);      // load + list evaluation + certified points' terms
+        atomicAdd(status + 9, pt_[2] - pt_[1]);      // the queued points
+        atomicAdd(status + 10, pt_[3] - pt_[2]);     // Adam + displacement
+        atomicAdd(status + 11, 1ull);
+    }
+#endif
+#undef LL_STAMP
 }
 
 // repulsion_loss(p) for K > MAXK (ifd_repulsion): loss [B], optional gradient and neighbour indices

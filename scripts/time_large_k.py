@@ -31,3 +31,10 @@ for k in ks:
         k, n, steps, dt * 1e3, per * 1e9, per / base,
         "" if k <= 1024 else "; %.1f list epochs per cloud, %.2f %% of the point-steps through the exact query" %
         (c["knn_rebuilds"] / float(n), 100.0 * c["knn_exact_evals"] / (float(n) * k * steps))))
+    if k > 1024 and c["prof_cycles"][3]:          # a -DIFD_PROF build: cloud 0's phase cycles per (non-first) step
+        pc = c["prof_cycles"]
+        print("        cloud 0, k cycles per step: list evaluation + certified terms %.1f | queued points %.1f | Adam %.1f" %
+              (pc[0] / pc[3] / 1e3, pc[1] / pc[3] / 1e3, pc[2] / pc[3] / 1e3))
+        if pc[6]:
+            print("        wave 0 of cloud 0: %.2f passes of the queued-point loop per step, %.1f k cycles per pass in the candidate loop, %.1f k in fill + merge"
+                  % (pc[6] / float(pc[3]), pc[4] / pc[6] / 1e3, pc[5] / pc[6] / 1e3))
