@@ -125,6 +125,7 @@ struct ifd_ctx {
     // read from the environment once, at creation (read_opt_env): bound of the cross-CU waits of split clouds, test hook
     unsigned int coop_timeout_ticks = 3000000000u;
     int test_drop_member = -1;
+    int test_no_morton = 0;        // measurement hook: ifd_prepare leaves the optimised points in draw order (the locality A/B through the whole pipeline)
     unsigned long long* d_status_out = nullptr;   // ifd_optimize_status: the status words as taken (atomic exchange) by status_take_kernel
     std::string err;
 };
@@ -254,6 +255,7 @@ bool bad_bk(int B, int K) { return B < 1 || K < 6 || K > LARGE_MAXK; }
 struct OptEnv {
     unsigned int coop_timeout_ticks;
     int test_drop_member;
+    int test_no_morton;
 };
 // the two sticky status words (overflow, time-out), taken and cleared atomically
 __global__ void status_take_kernel(unsigned long long* __restrict__ st, unsigned long long* __restrict__ out) {
@@ -265,9 +267,13 @@ OptEnv read_opt_env() {
     if (const char* t = std::getenv("IFD_COOP_TIMEOUT_MS")) { const double x = std::atof(t); if (x > 0.0) ms = x; }
     o.coop_timeout_ticks = (unsigned int)std::min(4.0e9, ms * 1.0e5);          // 100 MHz wall clock (s_memrealtime)
     o.test_drop_member = -1;
+    o.test_no_morton = 0;
     const char* en = std::getenv("IFD_ENABLE_TEST_HOOKS");
     if (en != nullptr && en[0] == '1')
+    {
         if (const char* d = std::getenv("IFD_TEST_COOP_DROP")) o.test_drop_member = std::atoi(d);
+        if (const char* d = std::getenv("IFD_TEST_NO_MORTON")) o.test_no_morton = d[0] == '1' ? 1 : 0;
+    }
     return o;
 }
 
@@ -505,7 +511,7 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess && !ctx->d_status_out) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status_out), 2 * sizeof(unsigned long long));
-    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; }
+    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; ctx->test_no_morton = oe.test_no_morton; }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_w), n_weights * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w, ctx->w.data(), n_weights * sizeof(float), hipMemcpyHostToDevice);
     {
@@ -603,6 +609,7 @@ int ifd_prepare(ifd_ctx* ctx, const float* pc, const uint8_t* keep_mask, int B, 
     a.cloud_base = (int)prm->cloud_index_base; a.n_sel = prm->n_sel; a.n_opt = prm->n_opt;
     a.padding_scale = prm->padding_scale; a.init_sigma = prm->init_sigma;
     a.seed_lo = (uint32_t)(prm->seed & 0xffffffffu); a.seed_hi = (uint32_t)(prm->seed >> 32);
+    a.no_morton = ctx->test_no_morton;
     hipError_t e = launch_prepare(pc, keep_mask, B, K, a, sel_idx, init_idx, noise, sel, t_per_cloud, init_points, n_kept,
                                   proc, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_prepare launch", e);
@@ -856,7 +863,7 @@ ifd_ctx* ifd_onet_create(const float* weights_host, size_t n_weights, int device
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess && !ctx->d_status_out) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status_out), 2 * sizeof(unsigned long long));
-    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; }
+    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; ctx->test_no_morton = oe.test_no_morton; }
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
     if (e == hipSuccess) e = configure_onet_kernels();

@@ -59,6 +59,7 @@ struct PrepArgs {
     int n_sel, n_opt;          // encoder subset size (600), optimised points per cloud (1024)
     float padding_scale, init_sigma;
     uint32_t seed_lo, seed_hi;
+    int no_morton;             // measurement hook (IFD_TEST_NO_MORTON with IFD_ENABLE_TEST_HOOKS=1, read at create): the library's own draws keep their draw order
 };
 constexpr int PREP_MAXK = 10000;     // largest input cloud (points) of ifd_sor / ifd_prepare (prep.hip: LDS of prepare_kernel)
 hipError_t configure_prep_kernels();

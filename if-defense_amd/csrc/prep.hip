@@ -162,7 +162,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
                                                                 int32_t* __restrict__ n_kept, float* __restrict__ proc_out) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     // the optimised points leave in Morton order when the draws are the library's own (see the end of the kernel)
-    const bool morton = init_idx == nullptr && noise == nullptr && A.n_opt <= PREP_SORT_MAX;
+    const bool morton = init_idx == nullptr && noise == nullptr && A.n_opt <= PREP_SORT_MAX && A.no_morton == 0;
     const int nkey = prep_nkey(K, morton ? A.n_opt : 0);
     float* P = fsm;                                                   // [K][3] kept points, then processed
     uint32_t* KEY = reinterpret_cast<uint32_t*>(P + 3 * K);           // [K] random keys for the subset ...
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const float* __re
 // (120,128 B at 10,000); prepare 16 K + 256 B (160,256 B at 10,000)
 static size_t sor_lds(int K) { return K <= SOR_NARROW_MAXK ? ((size_t)4 * K + 16) * sizeof(double) : (size_t)12 * K + 4 * (K & 1) + 128; }
 static size_t prep_lds(int K, int n_opt = 0) {         // n_opt: the Morton keys of the optimised points share the subset keys' array
-    return (size_t)12 * K + (size_t)4 * prep_nkey(K, n_opt <= PREP_SORT_MAX ? n_opt : 0) + 64 * 4;
+    return (size_t)12 * K + (size_t)4 * prep_nkey(K, n_opt <= PREP_SORT_MAX ? n_opt : 0) + 64 * 4;      // (sized for the sorted case whatever the hook says)
 }
 
 hipError_t configure_prep_kernels() {
