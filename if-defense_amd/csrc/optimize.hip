@@ -291,7 +291,9 @@ static LargeLists large_lists_at(void* base, int B, int K) {
     L.scal = reinterpret_cast<float*>(c);
     return L;
 }
-constexpr size_t LARGE_LISTS_LDS = (size_t)(LARGE_LDS_MAXK + 1) * 16 + (size_t)LARGE_LDS_MAXK * (8 + 4 + 4 + 2 + 4) + 64 * 4 + 16;   // 155,936 B
+constexpr int LL_BLK = 128;                         // candidates are walked in blocks of 128 consecutive indices, each with a bounding box
+constexpr size_t LARGE_LISTS_LDS = (size_t)(LARGE_LDS_MAXK + 1) * 16 + (size_t)LARGE_LDS_MAXK * (8 + 4 + 4 + 2 + 4) + 64 * 4 + 16 +
+                                   (LARGE_LDS_MAXK / LL_BLK) * 8 * 4;                       // 156,960 B
 
 __device__ __forceinline__ float ll_dist2(const f32x4& a, const f32x4& b) {
     const float ex = a.x - b.x, ey = a.y - b.y, ez = a.z - b.z;
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
     int* qn = reinterpret_cast<int*>(scratch + 64);                                   // queue length (+ 3 pad)
     float* qd5 = reinterpret_cast<float*>(qn + 4);                                    // [LARGE_LDS_MAXK] upper bound of the queued point's squared 5th distance
     uint16_t* queue = reinterpret_cast<uint16_t*>(qd5 + LARGE_LDS_MAXK);              // [LARGE_LDS_MAXK]
+    float* BB = reinterpret_cast<float*>(queue + LARGE_LDS_MAXK);                     // [K / LL_BLK][8] bounding boxes of the index blocks {min xyz, -, max xyz, -}
     const size_t cb = (size_t)cloud * K;
     float* pc = p + cb * 3;
     constexpr int PPT = LARGE_LDS_MAXK / LARGE_THREADS;                               // 4 points per thread
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
     for (int r = 0; r < PPT; ++r) {
         const int pt = tid + r * LARGE_THREADS;
         if (pt < K) X[pt] = f32x4{pc[3 * pt], pc[3 * pt + 1], pc[3 * pt + 2], 0.f};
-        Fz.xy[pt] = 0; Fz.z[pt] = 0; RL[pt] = 0.f;
+        Fz.xy[pt] = 0; Fz.z[pt] = 0; RL[pt] = 0.f; qd5[pt] = -1.f;
     }
     if (tid == 0) { *qn = 0; X[LL_DUMMY] = f32x4{1e18f, 1e18f, 1e18f, 0.f}; }
 #ifdef IFD_PROF
@@ -438,8 +441,8 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
                 float ua, ub;
                 oka = va && ll_certify(qa, X[ia], L.cert[cb + ia], (d_now - L.dbase[cb + ia].x) * 1.00001f, ta, ua);
                 okb = vb && ll_certify(qb, X[ib], L.cert[cb + ib], (d_now - L.dbase[cb + ib].x) * 1.00001f, tb, ub);
-                if (va && !oka) { const int at = atomicAdd(qn, 1); queue[at] = (uint16_t)pa; qd5[at] = ua; }
-                if (vb && !okb) { const int at = atomicAdd(qn, 1); queue[at] = (uint16_t)pb; qd5[at] = ub; }
+                if (va && !oka) qd5[pa] = fmaxf(ua, 0.f);                              // queued (by point: the queue itself is compacted in
+                if (vb && !okb) qd5[pb] = fmaxf(ub, 0.f);                              // index order below)
             }
             float la, lb;
             rep_point2(X, Fz, K, oka ? pa : K, okb ? pb : K, ta, tb, rc, la, lb);
@@ -457,6 +460,41 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
         //      full is dropped and caps the certified radius at its distance (every point nearer than the nearest dropped hit is in the
         //      list).  The four top-5 are merged by (distance, index) through DPP, so every lane ends with the scan's exact answer.
         //      A list that came out useless (no bound to start from, or rho <= r5) is collected once more around the exact d5. -------
+        // The queue in INDEX order (a block-wide prefix sum over the per-point flags, four consecutive points per thread): the initial points
+        // leave ifd_prepare in Morton order and move little, so the 16 points a wave takes are neighbours in space - and so are the 128
+        // consecutive candidates of a block, whose bounding box lets the whole wave skip it when none of its points' balls reaches it.
+        {
+            int mine = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine += (4 * tid + e < K && qd5[4 * tid + e] >= 0.f) ? 1 : 0;
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            int* wtot = reinterpret_cast<int*>(scratch);
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < LARGE_THREADS / 64; ++w) { const int tw = wtot[w]; before += w < wave ? tw : 0; all += tw; }
+            int at = before + incl - mine;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * tid + e < K && qd5[4 * tid + e] >= 0.f) queue[at++] = (uint16_t)(4 * tid + e);
+            if (tid == 0) *qn = all;
+            // bounding boxes of the index blocks (wave w: blocks w, w + 16; two points per lane)
+            for (int b = wave; b * LL_BLK < K; b += LARGE_THREADS / 64) {
+                const int j0 = b * LL_BLK + lane, j1 = j0 + 64;
+                const f32x4 p0 = X[min(j0, K - 1)], p1 = X[min(j1, K - 1)];            // (a clamped index repeats a point of the block or of an earlier one: the box only grows)
+                const float lo[3] = {fminf(p0.x, p1.x), fminf(p0.y, p1.y), fminf(p0.z, p1.z)};
+                const float hi[3] = {fmaxf(p0.x, p1.x), fmaxf(p0.y, p1.y), fmaxf(p0.z, p1.z)};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float mn = -wave_max(-lo[a]), mx = wave_max(hi[a]);
+                    if (lane == 0) { BB[8 * b + a] = mn; BB[8 * b + 4 + a] = mx; }
+                }
+            }
+            __syncthreads();
+        }
         const int nq = *qn;
         const int sub = lane & 3;
 #pragma unroll 1
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
             float alpha = act ? L.dbase[cb + i].y : LL_ALPHA;
             // d5 <= tins: only candidates this near can be among the five nearest - the sorted insertion (~30 vector instructions, and a
             // wave runs it whenever ONE of its 64 lanes needs it) is kept off the other ~2000 (measured: 486 -> see r06_time_large_k*)
-            float tins = act ? qd5[min(qi, LARGE_LDS_MAXK - 1)] : 0.f;
+            float tins = act ? qd5[i] : 0.f;
             float r2 = alpha * tins;
             if (!(r2 < 1e30f)) { r2 = 0.f; tins = INFINITY; }                          // (no usable bound: the second pass sets the radius)
             Top5 t;
@@ -490,7 +528,14 @@ __global__ __launch_bounds__(LARGE_THREADS) void large_step_lists_kernel(float* 
                 // and the sorted insertion likewise: 345 - 486 cycles per candidate and wave, measured.)
                 const float lim = fmaxf(r2, tins);                                     // (tins = INF without a bound: every candidate is looked at)
 #pragma unroll 1
-                for (int w0 = 0; w0 < K; w0 += 128) {
+                for (int w0 = 0; w0 < K; w0 += LL_BLK) {
+                    {   // squared distance from the point to the block's box: beyond lim for every point of the wave -> nothing to find there
+                        const float* bb = BB + 8 * (w0 / LL_BLK);
+                        const float ex = fmaxf(fmaxf(bb[0] - xi.x, xi.x - bb[4]), 0.f), ey = fmaxf(fmaxf(bb[1] - xi.y, xi.y - bb[5]), 0.f),
+                                    ez = fmaxf(fmaxf(bb[2] - xi.z, xi.z - bb[6]), 0.f);
+                        const float lb2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex)) * 0.99999f;     // (rounded down: a lower bound)
+                        if (__ballot(act && lb2 <= lim) == 0ull) continue;
+                    }
                     unsigned int hit = 0u;
 #pragma unroll 8
                     for (int bb = 0; bb < 32; ++bb) {

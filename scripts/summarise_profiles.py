@@ -75,7 +75,8 @@ def durations_by_grid():
     if f:
         for r in csv.DictReader(open(f)):
             if "optimize_kernel" in r["Kernel_Name"] and "onet" not in r["Kernel_Name"]:
-                wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+                # (the kernel trace names the dimensions one by one, the counter files give the products)
+                wgs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]) // int(r["Workgroup_Size"])
                 d.setdefault(wgs, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     return {k: sum(v) / len(v) for k, v in d.items()}
 
