@@ -3,8 +3,8 @@
 # scripts/stamp_round6.sh copies the results into profiles/ afterwards (build container).
 mkdir -p gpurun_out
 R=$(pwd)
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "config3 or morton" > gpurun_out/r06_gpu_tests_config3.log 2>&1
-tail -3 gpurun_out/r06_gpu_tests_config3.log
+timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/r06_gpu_tests.log 2>&1
+tail -3 gpurun_out/r06_gpu_tests.log
 # rocprofv3: kernel statistics + the HBM-side traffic of the optimiser, per launch shape, f32 and bf16x6 (separate --pmc passes)
 bash scripts/collect_profiles.sh r06 > gpurun_out/collect_r06.log 2>&1
 bash scripts/collect_profiles.sh r06_bf16x6 bf16x6 > gpurun_out/collect_r06_bf16x6.log 2>&1
@@ -26,4 +26,6 @@ done; done) > gpurun_out/r06_strong_scaling_proxies.jsonl 2>&1
 cat gpurun_out/r06_strong_scaling_proxies.jsonl
 python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
 python bench.py --streamed --no-extras --no-cpu-baseline > gpurun_out/r06_bench_streamed.json 2>/dev/null
+IFD_LIB=$R/if-defense_amd/csrc/libifd_v_prof.so timeout 300 python scripts/time_large_k.py 256 1024 2048 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_time_large_k_prof.txt
+(timeout 300 python scripts/time_large_k.py 256 1024 2048 4096; IFD_LARGE_STEPS=501 timeout 300 python scripts/time_large_k.py 256 1024 2048; IFD_LARGE_SCAN=1 timeout 300 python scripts/time_large_k.py 256 1024 2048 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_time_large_k.txt
 cut -c1-300 gpurun_out/r06_bench.json
