@@ -199,14 +199,14 @@ typedef struct ifd_opt_params {
                              split launches on one GPU at the same time (set 1 there). */
     int32_t planes_shared;/* measurement only: != 0 makes every cloud read the planes of cloud 0 (the tap gathers then hit in
                              L2: scripts/ab_planes.py prices the gather traffic this way) */
-    int32_t knn_reference_form; /* validation only (K <= 1024): != 0 ranks the neighbours exactly like the reference - float32 expanded form
+    int32_t knn_reference_form; /* validation only: != 0 ranks the neighbours exactly like the reference - float32 expanded form
                              |a|^2 + |b|^2 - 2 a.b in torch's accumulation order, top-6, column 0 dropped whatever it is
                              (ConvONet/defense/pn_utils.py:72-83), by brute force every step - instead of the exact 5-NN of direct
                              differences.  The reference's form swaps candidates closer than its ~1e-7 noise and, for pairs of points
                              closer than ~1.5e-4, keeps "self" as a neighbour and drops the pair's term; the product path does not.
                              (topk's order among EQUAL distances is restated for rows of >= 384 values - torch's partial_sort path,
                              which 1024-point clouds take; shorter rows go through nth_element there and ties may differ.) */
-    int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers in the persistent kernel (K <= 1024):
+    int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers (every K for ifd_optimize; K <= 1024 for ifd_onet_optimize):
                              0 = f32 MFMA (v_mfma_f32_16x16x4_f32: bit-equal to an fmaf chain) - the default;
                              1 = "bf16x6": both operands split exactly into three bf16 pieces, six piece products on the bf16
                                  matrix core, f32 accumulation - f32-equivalent (dropped terms <= 2^-26 of a product, one
@@ -224,8 +224,11 @@ typedef struct ifd_opt_params {
  * loss_batch_per_cloud (optional) [B] int32: overrides prm->loss_batch per cloud, so clouds that belong to
  * different reference batches (the last batch of a file is shorter) can share one launch.
  * 6 <= K <= 10000.  Up to 1024 points a cloud runs in the persistent one-launch kernel; 1025 ... 10000 points take two
- * launches per Adam step (decoder gradient; exact brute-force 5-NN + repulsion + Adam), same arithmetic, and
- * knn_scan_every_step / the counters below do not apply. */
+ * launches per Adam step (decoder gradient on the persistent kernel's tile, in the requested precision; exact 5-NN +
+ * repulsion + Adam), same arithmetic.  Up to 4096 points the second launch keeps certified neighbour lists of its own
+ * (bit-identical to the brute-force scan, which knn_scan_every_step selects and which clouds beyond 4096 points always
+ * take); knn_reference_form applies at every size.  Counters of this path: [0] whole-cloud list builds (one per cloud
+ * and call), [5] point-steps whose certificate did not hold and that were resolved by the exact query. */
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
                  const ifd_opt_params* prm, const int32_t* loss_batch_per_cloud,
                  float* m, float* v, float* loss, void* stream);
