@@ -620,6 +620,9 @@ def main():
     ap.add_argument("--workload", choices=("convonet-opt", "onet-opt"), default="convonet-opt",
                     help="convonet-opt = the BASELINE metric (default); onet-opt = the ONet-Opt decoder variant "
                          "(BASELINE config #1 model, SURVEY N4) at 500 iterations - an extra line, not the headline")
+    ap.add_argument("--backend", default=None, help="TEST ONLY: torch.distributed backend (default: nccl = RCCL on GPUs); 'gloo' lets two "
+                    "ranks share ONE GPU (tests/test_gpu_two_processes.py runs the N > 1 code path of this script that way)")
+    ap.add_argument("--device", default=None, help="TEST ONLY: the device of every rank (default: cuda:LOCAL_RANK)")
     ap.add_argument("--profile-precision", choices=("f32", "bf16x6", "bf16x3"), default="f32",
                     help="PROFILING ONLY (scripts/pmc_bench.sh): run the timed passes in a split-precision mode; the line is then labelled "
                          "as such in metric / dtype / config.arith and is not the BASELINE metric")
@@ -633,7 +636,7 @@ def main():
     from ifdefense_amd import dist as D
     import torch.distributed as dist
 
-    rank, world, local = D.init_from_env("gloo" if a.dry_run else None)
+    rank, world, local = D.init_from_env("gloo" if a.dry_run else a.backend)
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (a.gpus, world))
     total = a.clouds * world if a.scaling == "weak" else a.clouds
@@ -656,8 +659,16 @@ def main():
         if not ok:
             raise SystemExit("dry run: the gathered array is not the concatenation of the ranks' shards")
         return
-    dev = torch.device("cuda", local)
+    dev = torch.device(a.device) if a.device else torch.device("cuda", local)
     torch.cuda.set_device(dev)
+
+    def reduce_max(seconds):
+        """max over the ranks of a host-side duration (RCCL reduces device tensors, gloo host tensors)"""
+        if not dist.is_initialized():
+            return float(seconds)
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
     my_clouds = synth_clouds(hi - lo, start=lo)                         # every rank synthesises only its own shard
     x = torch.from_numpy(my_clouds).to(dev)                             # resident in HBM before timing
     if onet:
@@ -716,11 +727,7 @@ def main():
     t0 = time.perf_counter()
     out = run_steps(a.steps)
     barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = reduce_max(time.perf_counter() - t0)
     assert out.shape == (total, K_POINTS, 3) and bool(torch.isfinite(out).all())
 
     kern_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
@@ -745,11 +752,10 @@ def main():
         t1 = time.perf_counter()
         so = strong_steps(a.steps)
         barrier()
-        t_strong = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(t_strong, op=dist.ReduceOp.MAX)
+        t_strong = reduce_max(time.perf_counter() - t1)
         assert so.shape == (a.clouds, K_POINTS, 3)
-        strong = {"value": round(a.clouds * a.steps / float(t_strong.item()), 2), "unit": "clouds/s", "scaling": "strong",
-                  "clouds_total": a.clouds, "clouds_per_gpu": s_per, "ms_per_step": round(float(t_strong.item()) / a.steps * 1e3, 2),
+        strong = {"value": round(a.clouds * a.steps / t_strong, 2), "unit": "clouds/s", "scaling": "strong",
+                  "clouds_total": a.clouds, "clouds_per_gpu": s_per, "ms_per_step": round(t_strong / a.steps * 1e3, 2),
                   "what": "ONE %d-cloud array sharded over the %d ranks (BASELINE configs #3 / #5), %d passes timed like the headline "
                           "(barrier + synchronize on both sides, max over ranks); the shard's partial round is split over 2 / 4 CUs per cloud" %
                           (a.clouds, world, a.steps)}

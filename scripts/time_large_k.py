@@ -35,6 +35,9 @@ for k in ks:
         pc = c["prof_cycles"]
         print("        cloud 0, k cycles per step: list evaluation + certified terms %.1f | queued points %.1f | Adam %.1f" %
               (pc[0] / pc[3] / 1e3, pc[1] / pc[3] / 1e3, pc[2] / pc[3] / 1e3))
+        if pc[7]:
+            print("        cloud 0, queued points by reason: keys 5 / 6 tie %d, no valid list (rho = 0) %d, certificate %d" %
+                  (pc[7] & 0xfffff, (pc[7] >> 20) & 0xfffff, pc[7] >> 40))
         if pc[6]:
             print("        wave 0 of cloud 0: %.2f passes of the queued-point loop per step, %.1f k cycles per pass in the candidate loop, %.1f k in fill + merge"
                   % (pc[6] / float(pc[3]), pc[4] / pc[6] / 1e3, pc[5] / pc[6] / 1e3))

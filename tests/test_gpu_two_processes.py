@@ -92,3 +92,26 @@ def test_two_processes_on_one_gpu(tmp_path, np_weights):
     assert r.returncode != 0 and not list(tmp_path.glob("done_rank*")), out
     assert "rank 1 failed on" in out and "-5" in out and "rank 0 stops: another rank failed" in out, out
     assert dt < 120, dt
+
+
+def test_bench_line_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path with real kernels (round 6): two ranks under the driver's launch line, gloo transport and both ranks on
+    cuda:0 (test-only flags; RCCL refuses two ranks on one device).  The weak-scaling line carries the STRONG-scaling figure too (one
+    array of --clouds clouds sharded over the ranks: BASELINE configs #3 / #5), both timed with barriers on both sides and the max over
+    the ranks."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IFD_SPLIT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--clouds", "40", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-extras", "--backend", "gloo", "--device", "cuda:0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["clouds_total"] == 80 and line["config"]["clouds_per_gpu"] == 40
+    st = line["strong_scaling"]
+    assert st["scaling"] == "strong" and st["clouds_total"] == 40 and st["clouds_per_gpu"] == 20 and st["value"] > 0
+    print("two ranks on one GPU: weak %.1f clouds/s (80 clouds), strong %.1f clouds/s (40 clouds)" % (line["value"], st["value"]))
