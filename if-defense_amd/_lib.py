@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("IFD_LIB") or os.path.join(HERE, "csrc", "libifd.so")
 IFD_OK = 0
 IFD_ERR_TIMEOUT = -5
 IFD_ERR_OVERFLOW = -6
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class IfdConfig(C.Structure):
@@ -61,6 +61,8 @@ SIGNATURES = {
     "ifd_encode_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ifd_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "ifd_decode_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
     "ifd_repulsion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "ifd_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
@@ -74,6 +76,8 @@ SIGNATURES = {
     "ifd_onet_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ifd_onet_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "ifd_onet_decode_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "ifd_onet_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(IfdOptParams),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ifd_onet_mesh_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(IfdMeshParams), C.c_void_p, C.c_void_p,

@@ -46,7 +46,7 @@ def _stale(target: str, deps) -> bool:
 # v_pk_*_f32 instructions, and a packed-f32 instruction whose consumer does not follow back to back occasionally delivers a wrong
 # result while the other wave of its SIMD streams bf16 MFMAs (scripts/pk_mfma_coexec.hip, profiles/r05_pk_mfma_coexec.txt);
 # tests/test_abi_cpu.py checks that the shipped kernels contain none.
-FILE_FLAGS = {"optimize_bf.hip": ["-fno-slp-vectorize"], "onet_bf.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"optimize_bf.hip": ["-fno-slp-vectorize"], "onet_bf.hip": ["-fno-slp-vectorize"], "decode_bf.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src: str, force: bool, extra=(), suffix="") -> str:

@@ -548,6 +548,7 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     if (e == hipSuccess) e = configure_unet_kernels();
     if (e == hipSuccess) e = configure_prep_kernels();
     if (e == hipSuccess) e = configure_optimize_kernels();
+    if (e == hipSuccess) e = configure_decode_bf_kernels();
     if (e != hipSuccess) {
         g_create_error = std::string("ifd_create: ") + hipGetErrorString(e);
         if (ctx->d_dec_img) (void)hipFree(ctx->d_dec_img);
@@ -656,15 +657,22 @@ int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_encode_planes", e);
 }
 
-int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,
-               void* stream) {
+int ifd_decode_ex(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, int precision, float* logits, float* dlogit_dp,
+                  void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_CONVONET) return fail(ctx, IFD_ERR_ARG, "ifd_decode: not a ConvONet context (use ifd_onet_decode)");
     if (!planes || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_decode: bad argument");
-    hipError_t e = launch_decode(ctx->d_dec_img, planes, p, B, K, logits, dlogit_dp, ctx->dc,
-                                 static_cast<hipStream_t>(stream));
+    if (precision < 0 || precision > 2) return fail(ctx, IFD_ERR_ARG, "ifd_decode_ex: precision must be 0 (f32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = precision == 0 ? launch_decode(ctx->d_dec_img, planes, p, B, K, logits, dlogit_dp, ctx->dc, s)
+                                  : launch_decode_bf(precision, ctx->d_dec_img_bf, planes, p, B, K, logits, dlogit_dp, ctx->dc, ctx->n_cu, s);
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_decode launch", e);
+}
+
+int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,
+               void* stream) {
+    return ifd_decode_ex(ctx, planes, p, B, K, 0, logits, dlogit_dp, stream);
 }
 
 int ifd_repulsion(ifd_ctx* ctx, const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx,
@@ -910,16 +918,24 @@ hipError_t onet_fold(ifd_ctx* ctx, const float* c, int B, hipStream_t s, float**
 }
 }  // namespace
 
-int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, float* logits, float* dlogit_dp, void* stream) {
+int ifd_onet_decode_ex(ifd_ctx* ctx, const float* c, const float* p, int B, int K, int precision, float* logits, float* dlogit_dp,
+                       void* stream) {
     if (!ctx) return IFD_ERR_ARG;
     IFD_ON_CTX_DEVICE(ctx);
     if (ctx->model != IFD_MODEL_ONET) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode: not an ONet context");
     if (!c || !p || !logits || B < 1 || K < 1) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode: bad argument");
+    if (precision < 0 || precision > 2) return fail(ctx, IFD_ERR_ARG, "ifd_onet_decode_ex: precision must be 0 (f32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* ab = nullptr;
     hipError_t e = onet_fold(ctx, c, B, s, &ab);
-    if (e == hipSuccess) e = launch_onet_decode(ctx->d_onet_img, ctx->d_onet_small, ab, p, B, K, logits, dlogit_dp, s);
+    if (e == hipSuccess)
+        e = precision == 0 ? launch_onet_decode(ctx->d_onet_img, ctx->d_onet_small, ab, p, B, K, logits, dlogit_dp, s)
+                           : launch_onet_decode_bf(precision, ctx->d_onet_img_bf, ctx->d_onet_small, ab, p, B, K, logits, dlogit_dp, s);
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_onet_decode", e);
+}
+
+int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, float* logits, float* dlogit_dp, void* stream) {
+    return ifd_onet_decode_ex(ctx, c, p, B, K, 0, logits, dlogit_dp, stream);
 }
 
 int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, const ifd_opt_params* prm,

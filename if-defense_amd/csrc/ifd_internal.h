@@ -80,6 +80,10 @@ hipError_t launch_adam_table(float* tab, int t0, int steps, float lr, hipStream_
 size_t knn_list_bytes(int B);
 hipError_t launch_decode(const float* dec_img, const float* planes, const float* p, int B, int K, float* logits,
                          float* dlogit_dp, DecConst dc, hipStream_t s);
+// ... in a split-precision mode (decode_bf.hip: the optimiser's own tile in MODE_SUM); dec_img_bf = the bf16 piece image
+hipError_t configure_decode_bf_kernels();
+hipError_t launch_decode_bf(int prec, const float* dec_img_bf, const float* planes, const float* p, int B, int K, float* logits, float* dlogit_dp,
+                            DecConst dc, int n_cu, hipStream_t s);
 hipError_t launch_repulsion(const float* p, int B, int K, float* loss, float* grad, int32_t* knn_idx, float radius,
                             float h, float eps, hipStream_t s);
 hipError_t launch_normalize(float* p, int B, int K, hipStream_t s);
@@ -123,6 +127,8 @@ hipError_t launch_onet_cbn(const float* w, const OnetDecOffsets& od, const float
                            hipStream_t s);
 hipError_t launch_onet_decode(const float* img, const float* small, const float* ab, const float* p, int B, int K,
                               float* logits, float* dlogit_dp, hipStream_t s);
+hipError_t launch_onet_decode_bf(int precision, const float* img_bf, const float* small, const float* ab, const float* p, int B, int K,
+                                 float* logits, float* dlogit_dp, hipStream_t s);      // onet_bf.hip
 // clouds of MAXK < K <= LARGE_MAXK points (ONet/opt_defense.py:27 has no limit): two launches per Adam step, ws as
 // large_ws_bytes
 hipError_t launch_onet_large_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,

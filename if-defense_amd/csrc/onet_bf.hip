@@ -11,6 +11,34 @@ namespace ifd {
 
 #include "onet_kernel.h"
 
+// generator.model.decode(p, z, c).logits (ONet/im2mesh/onet/models/decoder.py:115-133) on the split-precision passes: ifd_onet_decode_ex
+template <int PREC>
+__global__ __launch_bounds__(OPT_THREADS, 2) void onet_decode_bf_kernel(const float* __restrict__ img, const float* __restrict__ small,
+                                                                         const float* __restrict__ ab, const float* __restrict__ p, int K,
+                                                                         float* __restrict__ logits, float* __restrict__ dlogit_dp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    asm volatile("" ::: "v255");                                       // (two waves per SIMD own the register file: see onet_grid_eval_kernel)
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    onet_prologue_bf(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);
+    const float* pc = p + (size_t)cloud * K * 3;
+    const int npass = (K + 127) >> 7;
+    for (int g = 0; g < npass; ++g) {
+        const int pt = g * 128 + wave * 16 + (lane & 15), tp = min(pt, K - 1);
+        float logit, bce, dx[3];
+        if (dlogit_dp != nullptr)
+            onet_pass_bf<OMODE_SUM, true, PREC>(img, smem, wave, lane, pc[3 * tp], pc[3 * tp + 1], pc[3 * tp + 2], 0.f, 1.f, logit, bce, dx);
+        else
+            onet_pass_bf<OMODE_SUM, false, PREC>(img, smem, wave, lane, pc[3 * tp], pc[3 * tp + 1], pc[3 * tp + 2], 0.f, 1.f, logit, bce, dx);
+        if (lane < 16 && pt < K) {
+            logits[(size_t)cloud * K + pt] = logit;
+            if (dlogit_dp != nullptr) {
+                float* o = dlogit_dp + ((size_t)cloud * K + pt) * 3;
+                o[0] = dx[0]; o[1] = dx[1]; o[2] = dx[2];
+            }
+        }
+    }
+}
+
 hipError_t configure_onet_bf_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);
@@ -20,6 +48,10 @@ hipError_t configure_onet_bf_kernels() {
     if (e != hipSuccess) return e;
     // (the grid-evaluation kernels too: the attribute is per DEVICE, and this runs under the context's device at every
     // ifd_onet_create - a process-wide "configured" flag in the launcher left a second GPU's launches unconfigured; round-5 advisor)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_decode_bf_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_decode_bf_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_grid_eval_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
     if (e != hipSuccess) return e;
@@ -34,6 +66,15 @@ hipError_t launch_onet_grid_eval_bf(int precision, const float* img_bf, const fl
         hipLaunchKernelGGL(onet_grid_eval_kernel<1>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, g, B, box);
     else
         hipLaunchKernelGGL(onet_grid_eval_kernel<2>, dim3(n_blocks), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, g, B, box);
+    return hipGetLastError();
+}
+
+hipError_t launch_onet_decode_bf(int precision, const float* img_bf, const float* small, const float* ab, const float* p, int B, int K,
+                                 float* logits, float* dlogit_dp, hipStream_t s) {
+    if (precision == 1)
+        hipLaunchKernelGGL(onet_decode_bf_kernel<1>, dim3(B), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, p, K, logits, dlogit_dp);
+    else
+        hipLaunchKernelGGL(onet_decode_bf_kernel<2>, dim3(B), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, p, K, logits, dlogit_dp);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ class Restorer:
             self.ctx = self.lib.ifd_create(w.ctypes.data, w.size, C.byref(cfg), self.device.index or 0)
         if not self.ctx:
             raise IfdError((self.lib.ifd_last_error(None) or b"ifd_create failed").decode())
-        self._fn_decode, self._fn_optimize = self.lib.ifd_decode, self.lib.ifd_optimize
+        self._fn_decode, self._fn_optimize = self.lib.ifd_decode_ex, self.lib.ifd_optimize
         self.n_sel = 600                  # encoder subset (convonet_3plane_mn40.yaml:7 pointcloud_n)
 
     def close(self):
@@ -200,16 +200,17 @@ class Restorer:
         return out
 
     # ---------------------------------------------------------------- call seams
-    def decode(self, p: torch.Tensor, c, want_grad: bool = False):
-        """generator.model.decode(p, c).logits -> [B,K]; with want_grad also d(sum logits)/dp [B,K,3]."""
+    def decode(self, p: torch.Tensor, c, want_grad: bool = False, precision=None):
+        """generator.model.decode(p, c).logits -> [B,K]; with want_grad also d(sum logits)/dp [B,K,3].  precision as in
+        optimize_points (None: the module default): the seam computes in the arithmetic the optimiser would (ifd_decode_ex)."""
         planes = self._cond(c)
         p = _f32(p, self.device)
         B, K = p.shape[:2]
         logits = torch.empty(B, K, device=self.device, dtype=torch.float32)
         grad = torch.empty(B, K, 3, device=self.device, dtype=torch.float32) if want_grad else None
         with torch.cuda.device(self.device):
-            self._check(self._fn_decode(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, logits.data_ptr(),
-                                            self._ptr(grad), self._stream()))
+            self._check(self._fn_decode(self.ctx, planes.data_ptr(), p.data_ptr(), B, K, precision_code(precision),
+                                            logits.data_ptr(), self._ptr(grad), self._stream()))
         return (logits, grad) if want_grad else logits
 
     def repulsion_loss(self, p: torch.Tensor, want_grad: bool = False, want_idx: bool = False):
@@ -388,7 +389,7 @@ class OnetRestorer(Restorer):
             self.ctx = self.lib.ifd_onet_create(w.ctypes.data, w.size, self.device.index or 0)
         if not self.ctx:
             raise IfdError((self.lib.ifd_last_error(None) or b"ifd_onet_create failed").decode())
-        self._fn_decode, self._fn_optimize = self.lib.ifd_onet_decode, self.lib.ifd_onet_optimize
+        self._fn_decode, self._fn_optimize = self.lib.ifd_onet_decode_ex, self.lib.ifd_onet_optimize
         self.n_sel = 300                  # onet_mn40.yaml:6 pointcloud_n
 
     def _cond(self, c) -> torch.Tensor:

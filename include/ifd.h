@@ -53,7 +53,8 @@ extern "C" {
 /* 2: ifd_opt_params grew (split, planes_shared - round 3), ifd_optimize_status and the two status codes below were added */
 /* 3: ifd_opt_params.precision (round 5) */
 /* 4: ifd_mesh_params.precision (round 5) */
-#define IFD_ABI_VERSION 4
+/* 5: ifd_decode_ex, ifd_onet_decode_ex (round 6; nothing else changed: a caller of ABI 4 only needs the new version number) */
+#define IFD_ABI_VERSION 5
 
 enum {
     IFD_OK = 0,
@@ -168,6 +169,11 @@ int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
  * logits [B,K]; dlogit_dp (optional, may be NULL) [B,K,3] = d(sum logits)/dp. */
 int ifd_decode(ifd_ctx* ctx, const float* planes, const float* p, int B, int K,
                float* logits, float* dlogit_dp, void* stream);
+/* ... in the arithmetic ifd_opt_params.precision names (0: ifd_decode itself; 1 = bf16x6, 2 = bf16x3: the optimiser's own
+ * split-precision tile evaluating sum(logits) instead of the loss), so that the seam and ifd_optimize agree in every mode.
+ * (The reference has one arithmetic; a maintainer binds ifd_decode.) */
+int ifd_decode_ex(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, int precision,
+                  float* logits, float* dlogit_dp, void* stream);
 
 /* repulsion_loss(p) (ConvONet/opt_defense.py:221 -> defense/repulsion_loss.py:18-54,
  * defense/pn_utils.py:64-83).  loss [B] = mean over K*5 of (r-d)*exp(-(d/h)^2);
@@ -299,6 +305,9 @@ int ifd_onet_encode(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud, 
  * c [B,512], p [B,K,3] -> logits [B,K]; dlogit_dp (optional) [B,K,3] = d(sum of logits)/dp. */
 int ifd_onet_decode(ifd_ctx* ctx, const float* c, const float* p, int B, int K, float* logits,
                     float* dlogit_dp, void* stream);
+/* ... with ifd_opt_params.precision's arithmetic (see ifd_decode_ex). */
+int ifd_onet_decode_ex(ifd_ctx* ctx, const float* c, const float* p, int B, int K, int precision, float* logits,
+                       float* dlogit_dp, void* stream);
 
 /* optimize_points (ONet/opt_defense.py:182-239); arguments as ifd_optimize with c [B,512] for the planes. */
 int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, const ifd_opt_params* prm,

@@ -1762,6 +1762,71 @@ def test_decode_second_weight_seed(np_weights):
         r.close()
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_decode_seam_in_split_precision(restorer, golden, planes2, oracle_weights, mode):
+    """ifd_decode_ex: the stand-alone decoder in the arithmetic of ifd_opt_params.precision (the optimiser's split-precision tile
+    evaluating sum(logits)).  bf16x6 to the f32 seam's bounds against the reference's logits and autograd gradient; bf16x3 (reduced:
+    three of the six piece products) to 2e-3 of the largest value.  Ragged point counts (a tile is 32 points), clouds of more than
+    1024 points, coordinates outside the cube, and the sharing of one cloud's tiles over several workgroups (few clouds) against one
+    workgroup per cloud (many clouds) bit for bit."""
+    from oracle import convonet_oracle as O
+    tl, tg = (1e-5, 1e-4) if mode == "bf16x6" else (2e-3, 2e-3)
+    p = torch.from_numpy(golden["init_points"][:2])
+    logits, grad = restorer.decode(p, planes2, want_grad=True, precision=mode)
+    el, eg = _rel(logits.cpu().numpy(), golden["dec_logits"]), _rel(grad.cpu().numpy(), golden["dec_dlogit_dp"])
+    print("%s seam: logits %.2e, gradient %.2e of the largest value" % (mode, el, eg))
+    assert el < tl and eg < tg
+    assert torch.equal(restorer.decode(p, planes2, precision=mode), logits)
+    f32 = restorer.decode(p, planes2, precision="f32")
+    assert not torch.equal(f32, logits)                           # (another arithmetic did run)
+    for K in (1, 31, 33, 100, 1000):
+        q = torch.from_numpy(golden["init_points"][:2, :K]).clone()
+        ref = O.decode_logits(oracle_weights, q, planes2).numpy()
+        got = restorer.decode(q, planes2, precision=mode).cpu().numpy()
+        assert got.shape == (2, K) and _rel(got, ref) < tl, K
+    g = torch.Generator().manual_seed(5)
+    q = (torch.rand(2, 1500, 3, generator=g) - 0.5) * 1.4         # beyond the cube (clamped => zero plane gradient) and K > 1024
+    qr = q.clone().requires_grad_()
+    ref = O.decode_logits(oracle_weights, qr, planes2)
+    ref.sum().backward()
+    lg, gr = restorer.decode(q, planes2, want_grad=True, precision=mode)
+    assert _rel(lg.cpu().numpy(), ref.detach().numpy()) < tl
+    dg = np.abs(gr.cpu().numpy() - qr.grad.numpy()).max(-1) / np.abs(qr.grad.numpy()).max()
+    print("%s seam, 3000 random points: gradient median %.2e, max %.2e, beyond the bound %d" % (mode, np.median(dg), dg.max(), (dg > tg).sum()))
+    if mode == "bf16x6":
+        assert dg.max() < tg
+    else:                                  # the reduced mode flips a ReLU mask where a pre-activation is within ~1e-3 of zero: count those
+        assert (dg > tg).sum() <= 6 and dg.max() < 5e-2 and np.median(dg) < 2e-4
+    # many clouds: one workgroup per cloud; two clouds: each cloud's tiles over many workgroups
+    B = 300
+    pm = q[:1].expand(B, -1, -1).contiguous()
+    cm = {k: v[:1].expand(B, -1, -1, -1).contiguous() for k, v in planes2.items()}
+    lm, gm = restorer.decode(pm, cm, want_grad=True, precision=mode)
+    assert torch.equal(lm[0], lg[0]) and torch.equal(lm[B - 1], lg[0]) and torch.equal(gm[B - 1], gr[0])
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_onet_decode_seam_in_split_precision(onet, og, golden, mode):
+    """ifd_onet_decode_ex: the ONet decoder seam on the split-precision passes of ifd_onet_optimize."""
+    tl = 1e-5 if mode == "bf16x6" else 2e-3
+    p = torch.from_numpy(golden["init_points"][:2])
+    c = torch.from_numpy(og["c"][:2])
+    logits, grad = onet.decode(p, c, want_grad=True, precision=mode)
+    el = _rel(logits.cpu().numpy(), og["dec_logits"])
+    dg = np.abs(grad.cpu().numpy() - og["dec_dlogit_dp"]).max(-1) / np.abs(og["dec_dlogit_dp"]).max()
+    print("%s ONet seam: logits %.2e; gradient: %d points beyond 1e-4, median %.2e, max %.2e" % (mode, el, (dg > 1e-4).sum(), np.median(dg), dg.max()))
+    assert el < tl
+    if mode == "bf16x6":                                           # (ReLU-boundary points as in the f32 test above)
+        assert (dg > 1e-4).sum() <= 3 and dg.max() < 2e-2 and np.median(dg) < 1e-6
+    else:
+        assert np.median(dg) < 2e-3 and dg.max() < 5e-2
+    assert torch.equal(onet.decode(p, c, precision=mode), logits)
+    assert not torch.equal(onet.decode(p, c, precision="f32"), logits)
+    for K in (1, 17, 129, 1000):
+        got = onet.decode(p[:, :K], c, precision=mode).cpu().numpy()
+        assert got.shape == (2, K) and _rel(got, og["dec_logits"][:, :K]) < tl, K
+
+
 def _philox4x32_10(k0, k1, c0, c1, c2, c3):
     """Philox-4x32-10 (Salmon et al. 2011) on uint32 numpy arrays - the generator of prep.hip / mesh.hip."""
     k0, k1 = np.uint64(k0), np.uint64(k1)
