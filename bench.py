@@ -524,15 +524,31 @@ def extras(dev):
             if steps == 101:
                 first101[k_opt] = per[k_opt]
             ck = r.counters()
+        # ... and on a file-sized batch (2304 clouds = nine rounds of the persistent kernel; pipeline.py hands a whole file to one call):
+        # with more clouds than CUs a list-step launch costs the AVERAGE cloud, not the slowest of 256
+        xf = torch.from_numpy(synth_clouds(9 * 256)).to(dev)
+        perf = {}
+        for k_opt in (1024, 2048):
+            prep = r.prepare(xf, r.sor(xf), n_sel=600, n_opt=k_opt, seed=1234)
+            planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=ITERATIONS + 1)
+            torch.cuda.synchronize()
+            perf[k_opt] = (time.perf_counter() - t0) / (9 * 256.0 * k_opt * (ITERATIONS + 1))
+            del prep, planes
         out["k2048"] = {"value": round(1.0 / (per[2048] * 2048 * (ITERATIONS + 1)), 2), "unit": "clouds/s (2048 optimised points each, optimiser only)",
                         "per_point_cost_vs_1024": round(per[2048] / per[1024], 2),
                         "per_point_cost_vs_1024_first_101_steps": round(first101[2048] / first101[1024], 2),
+                        "per_point_cost_vs_1024_file_sized_batch": round(perf[2048] / perf[1024], 2),
+                        "value_file_sized_batch": round(1.0 / (perf[2048] * 2048 * (ITERATIONS + 1)), 2),
                         "whole_cloud_list_builds_per_cloud": round(ck["knn_rebuilds"] / 256.0, 2),
                         "exact_query_fraction": round(ck["knn_exact_evals"] / (256.0 * 2048 * (ITERATIONS + 1)), 5),
                         "what": "ifd_optimize on 256 clouds x 2048 points (two launches per Adam step: the persistent kernel's decoder tile, then certified "
                                 "neighbour lists + repulsion + Adam: DESIGN section 4.6), all 501 steps, nothing scaled; per_point_cost_vs_1024 = time per "
                                 "point and step over the persistent kernel's on 256 clouds x 1024 x 501 steps (and over the first 101 steps of both, where "
-                                "the persistent kernel still rebuilds its lists often)"}
+                                "the persistent kernel still rebuilds its lists often); _file_sized_batch: the same ratio on 2304 clouds in one call, "
+                                "where a list-step launch costs its average cloud instead of the slowest of 256 (lock-step launches)"}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["k2048"] = {"error": str(e)[:200]}
