@@ -969,10 +969,11 @@ int ifd_onet_optimize(ifd_ctx* ctx, const float* c, float* p, int B, int K, cons
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters + STATUS_TIMEOUT_CUR, 0, sizeof(unsigned long long), s);
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, s);
+    a.precision = prm->precision;
     if (e == hipSuccess && large)
-        e = launch_onet_large_optimize(ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
-                                       ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K, a, s);
-    else if (e == hipSuccess && prm->precision != 0)      // (clouds beyond 1024 points: the launch-per-step path has the f32 pass only)
+        e = launch_onet_large_optimize(prm->precision != 0 ? ctx->d_onet_img_bf : ctx->d_onet_img, ctx->d_onet_small, ab, p, m, v, loss,
+                                       loss_batch_per_cloud, ctx->ws, ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K, a, s);
+    else if (e == hipSuccess && prm->precision != 0)
         e = launch_onet_optimize_bf(prm->precision, ctx->d_onet_img_bf, ctx->d_onet_small, ab, p, m, v, loss, loss_batch_per_cloud,
                                     static_cast<uint16_t*>(ctx->ws), ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K,
                                     a, s);

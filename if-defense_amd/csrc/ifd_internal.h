@@ -127,6 +127,9 @@ hipError_t launch_onet_cbn(const float* w, const OnetDecOffsets& od, const float
                            hipStream_t s);
 hipError_t launch_onet_decode(const float* img, const float* small, const float* ab, const float* p, int B, int K,
                               float* logits, float* dlogit_dp, hipStream_t s);
+hipError_t launch_onet_large_occupancy_bf(int precision, const float* img_bf, const float* small, const float* ab, const float* p, int B,
+                                          int parts, int K, const int32_t* loss_batch_per_cloud, int loss_batch, float thr, void* G,
+                                          hipStream_t s);                               // onet_bf.hip
 hipError_t launch_onet_decode_bf(int precision, const float* img_bf, const float* small, const float* ab, const float* p, int B, int K,
                                  float* logits, float* dlogit_dp, hipStream_t s);      // onet_bf.hip
 // clouds of MAXK < K <= LARGE_MAXK points (ONet/opt_defense.py:27 has no limit): two launches per Adam step, ws as

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_large_occupancy_kernel(
     }
 }
 
+// (a.precision != 0: img = the bf16 piece image, the occupancy half on onet_bf.hip's split-precision pass)
 hipError_t launch_onet_large_optimize(const float* img, const float* small, const float* ab, float* p, float* m, float* v,
                                       float* loss, const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
                                       const float* adam_tab, int B, int K, const OptArgs& a, hipStream_t s) {
@@ -264,9 +265,14 @@ hipError_t launch_onet_large_optimize(const float* img, const float* small, cons
     const int npass = (K + 127) >> 7;
     const int parts = B >= 256 ? 1 : min(npass, max(1, 512 / B));        // enough workgroups to fill the GPU with few clouds
     for (int step = 0; step < a.steps; ++step) {
-        hipLaunchKernelGGL(onet_large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, p, K,
-                           loss_batch_per_cloud, a.loss_batch, a.threshold, G);
-        hipError_t e = launch_large_step(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a,
+        hipError_t e = hipSuccess;
+        if (a.precision != 0)
+            e = launch_onet_large_occupancy_bf(a.precision, img, small, ab, p, B, parts, K, loss_batch_per_cloud, a.loss_batch, a.threshold, G, s);
+        else
+            hipLaunchKernelGGL(onet_large_occupancy_kernel, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img, small, ab, p, K,
+                               loss_batch_per_cloud, a.loss_batch, a.threshold, G);
+        if (e != hipSuccess) return e;
+        e = launch_large_step(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a,
                                          step == a.steps - 1 ? loss : nullptr, f_ws, list_ws, counters, s);
         if (e != hipSuccess) return e;
     }

@@ -39,6 +39,40 @@ __global__ __launch_bounds__(OPT_THREADS, 2) void onet_decode_bf_kernel(const fl
     }
 }
 
+// The occupancy half of a step of the launch-per-step path (clouds of more than 1024 points; onet.hip onet_large_occupancy_kernel)
+// on the split-precision pass
+template <int PREC>
+__global__ __launch_bounds__(OPT_THREADS, 2) void onet_large_occupancy_bf_kernel(
+    const float* __restrict__ img, const float* __restrict__ small, const float* __restrict__ ab, const float* __restrict__ p,
+    int K, const int32_t* __restrict__ loss_batch_per_cloud, int loss_batch, float thr, f32x4* __restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    asm volatile("" ::: "v255");
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    onet_prologue_bf(img, small, ab + (size_t)cloud * ONET_NCBN * 2 * ONET_H, smem, tid, OPT_THREADS, wave, lane);
+    const float* pc = p + (size_t)cloud * K * 3;
+    const int lb = loss_batch_per_cloud ? loss_batch_per_cloud[cloud] : loss_batch;
+    const float inv_lb = 1.0f / (float)lb;
+    const int npass = (K + 127) >> 7;
+    for (int g = blockIdx.y; g < npass; g += gridDim.y) {          // (block-uniform trip count: the pass syncs the block)
+        const int pt = g * 128 + wave * 16 + (lane & 15), tp = min(pt, K - 1);
+        float logit, bce, dx[3];
+        onet_pass_bf<OMODE_OPT, true, PREC>(img, smem, wave, lane, pc[3 * tp], pc[3 * tp + 1], pc[3 * tp + 2], thr, inv_lb, logit, bce, dx);
+        if (lane < 16 && pt < K) G[(size_t)cloud * K + pt] = f32x4{dx[0], dx[1], dx[2], bce};
+    }
+}
+
+hipError_t launch_onet_large_occupancy_bf(int precision, const float* img_bf, const float* small, const float* ab, const float* p, int B,
+                                          int parts, int K, const int32_t* loss_batch_per_cloud, int loss_batch, float thr, void* G,
+                                          hipStream_t s) {
+    if (precision == 1)
+        hipLaunchKernelGGL(onet_large_occupancy_bf_kernel<1>, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, p, K,
+                           loss_batch_per_cloud, loss_batch, thr, static_cast<f32x4*>(G));
+    else
+        hipLaunchKernelGGL(onet_large_occupancy_bf_kernel<2>, dim3(B, parts), dim3(OPT_THREADS), ONET_DEC_LDS, s, img_bf, small, ab, p, K,
+                           loss_batch_per_cloud, loss_batch, thr, static_cast<f32x4*>(G));
+    return hipGetLastError();
+}
+
 hipError_t configure_onet_bf_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_optimize_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_OPT_LDS);
@@ -48,6 +82,10 @@ hipError_t configure_onet_bf_kernels() {
     if (e != hipSuccess) return e;
     // (the grid-evaluation kernels too: the attribute is per DEVICE, and this runs under the context's device at every
     // ifd_onet_create - a process-wide "configured" flag in the launcher left a second GPU's launches unconfigured; round-5 advisor)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_large_occupancy_bf_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_large_occupancy_bf_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_decode_bf_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(onet_decode_bf_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ONET_DEC_LDS);

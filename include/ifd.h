@@ -212,7 +212,7 @@ typedef struct ifd_opt_params {
                              closer than ~1.5e-4, keeps "self" as a neighbour and drops the pair's term; the product path does not.
                              (topk's order among EQUAL distances is restated for rows of >= 384 values - torch's partial_sort path,
                              which 1024-point clouds take; shorter rows go through nth_element there and ties may differ.) */
-    int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers (every K for ifd_optimize; K <= 1024 for ifd_onet_optimize):
+    int32_t precision;    /* arithmetic of the decoder's 32 x 32 layers (the 256 x 256 ones of ifd_onet_optimize; every K):
                              0 = f32 MFMA (v_mfma_f32_16x16x4_f32: bit-equal to an fmaf chain) - the default;
                              1 = "bf16x6": both operands split exactly into three bf16 pieces, six piece products on the bf16
                                  matrix core, f32 accumulation - f32-equivalent (dropped terms <= 2^-26 of a product, one

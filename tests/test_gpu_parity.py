@@ -1370,10 +1370,12 @@ def test_onet_p1_teacher_forced_and_p2_free_running(onet, og):
     np.testing.assert_allclose(loss[:, 1].mean() * 500.0, og["traj0_loss"][1], rtol=1e-5)
 
 
-def test_onet_large_clouds_more_than_1024_points(onet, og, golden):
+@pytest.mark.both_precisions
+def test_onet_large_clouds_more_than_1024_points(onet, og, golden, precision_mode):
     """ONet-Opt beyond the persistent kernel's 1024 points (ONet/opt_defense.py:27 takes any --sample_npoint): the
-    two-launch-per-step path (onet.hip onet_large_occupancy_kernel + the shared large_step_kernel) against the ONet oracle -
-    teacher-forced Adam steps from the oracle's trajectory and a short free run with normalisation."""
+    two-launch-per-step path (onet.hip onet_large_occupancy_kernel / onet_bf.hip's split-precision one + the shared step kernels)
+    against the ONet oracle - teacher-forced Adam steps from the oracle's trajectory and a short free run with normalisation.
+    In both precisions (f32 and the f32-equivalent bf16x6), and the two DO differ (the mode reaches this path)."""
     from oracle import convonet_oracle as O
     from oracle import onet_oracle as OO
     w = OO.to_torch(OO.make_random_weights(0))
@@ -1407,6 +1409,9 @@ def test_onet_large_clouds_more_than_1024_points(onet, og, golden):
         max_off, max_err = {1025: (2, 1e-5), 2048: (8, 1.2e-3)}[K]          # 2x the measured 0 / 4, 2.6e-6 / 5.7e-4
         assert (err > 2e-5).sum() <= max_off and err.max() < max_err, (K, int((err > 2e-5).sum()), float(err.max()))
         assert abs(float(got.norm(dim=-1).max()) - 1.0) < 1e-5
+        other = onet.optimize_points(init, c, rep_weight=500.0, iterations=3, normalize=True,
+                                     precision="bf16x6" if precision_mode == "f32" else "f32")
+        assert not torch.equal(other, got) and float((other - got).abs().max()) < 1.2e-3
 
 
 def test_onet_large_clouds_beyond_4096_points(onet, og):
