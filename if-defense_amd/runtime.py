@@ -309,7 +309,7 @@ class Restorer:
                                              knn_scan_every_step=scan, precision=precision, check=check)
                 t = nxt
                 continue
-            prob = float(torch.sigmoid(self.decode(p, c)).mean())               # occ_value of iteration t (pre-update points)
+            prob = float(torch.sigmoid(self.decode(p, c, precision=precision)).mean())   # occ_value of iteration t (pre-update points)
             last = t + 1 == n_steps
             p, st, loss = self.optimize_points(p, c, rep_weight=rep_weight, steps=1, lr=lr, loss_batch=loss_batch,
                                                normalize=normalize and last, state=st, return_state=True, return_loss=True,
