@@ -547,8 +547,9 @@ def extras(dev):
                         "what": "ifd_optimize on 256 clouds x 2048 points (two launches per Adam step: the persistent kernel's decoder tile, then certified "
                                 "neighbour lists + repulsion + Adam: DESIGN section 4.6), all 501 steps, nothing scaled; per_point_cost_vs_1024 = time per "
                                 "point and step over the persistent kernel's on 256 clouds x 1024 x 501 steps (and over the first 101 steps of both, where "
-                                "the persistent kernel still rebuilds its lists often); _file_sized_batch: the same ratio on 2304 clouds in one call, "
-                                "where a list-step launch costs its average cloud instead of the slowest of 256 (lock-step launches)"}
+                                "the persistent kernel still rebuilds its lists often); _file_sized_batch: the same ratio on 2304 clouds in one call "
+                                "(a launch ends with its slowest cloud; batches go as up to four stream groups that fill each other's idle CUs, "
+                                "and with more clouds than CUs a launch costs nearer its average cloud)"}
         r.close()
     except Exception as e:      # noqa: BLE001
         out["k2048"] = {"error": str(e)[:200]}

@@ -85,6 +85,8 @@ const WeightMap& wmap() {
 
 }  // namespace
 
+constexpr int LARGE_MAX_GROUPS = 4;   // stream groups of the launch-per-step path (large_optimize_in_groups)
+
 struct ifd_ctx {
     int device = 0;
     ifd_config cfg{};
@@ -125,6 +127,10 @@ struct ifd_ctx {
     // read from the environment once, at creation (read_opt_env): bound of the cross-CU waits of split clouds, test hook
     unsigned int coop_timeout_ticks = 3000000000u;
     int test_drop_member = -1;
+    int test_large_groups = 0;     // measurement hook: stream groups of the launch-per-step path (0 = automatic; large_groups_of)
+    // clouds of more than 1024 points: side streams + fork / join events of the stream groups (run_large_in_groups), created on first use
+    hipStream_t large_side[LARGE_MAX_GROUPS - 1] = {};
+    hipEvent_t large_fork = nullptr, large_join[LARGE_MAX_GROUPS - 1] = {};
     int test_no_morton = 0;        // measurement hook: ifd_prepare leaves the optimised points in draw order (the locality A/B through the whole pipeline)
     unsigned long long* d_status_out = nullptr;   // ifd_optimize_status: the status words as taken (atomic exchange) by status_take_kernel
     std::string err;
@@ -256,6 +262,7 @@ struct OptEnv {
     unsigned int coop_timeout_ticks;
     int test_drop_member;
     int test_no_morton;
+    int test_large_groups;
 };
 // the two sticky status words (overflow, time-out), taken and cleared atomically
 __global__ void status_take_kernel(unsigned long long* __restrict__ st, unsigned long long* __restrict__ out) {
@@ -268,11 +275,13 @@ OptEnv read_opt_env() {
     o.coop_timeout_ticks = (unsigned int)std::min(4.0e9, ms * 1.0e5);          // 100 MHz wall clock (s_memrealtime)
     o.test_drop_member = -1;
     o.test_no_morton = 0;
+    o.test_large_groups = 0;
     const char* en = std::getenv("IFD_ENABLE_TEST_HOOKS");
     if (en != nullptr && en[0] == '1')
     {
         if (const char* d = std::getenv("IFD_TEST_COOP_DROP")) o.test_drop_member = std::atoi(d);
         if (const char* d = std::getenv("IFD_TEST_NO_MORTON")) o.test_no_morton = d[0] == '1' ? 1 : 0;
+        if (const char* d = std::getenv("IFD_TEST_LARGE_GROUPS")) o.test_large_groups = std::atoi(d);
     }
     return o;
 }
@@ -511,7 +520,7 @@ ifd_ctx* ifd_create(const float* weights_host, size_t n_weights, const ifd_confi
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, N_COUNTERS_ALLOC * sizeof(unsigned long long));
     if (e == hipSuccess && !ctx->d_status_out) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status_out), 2 * sizeof(unsigned long long));
-    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; ctx->test_no_morton = oe.test_no_morton; }
+    { const OptEnv oe = read_opt_env(); ctx->coop_timeout_ticks = oe.coop_timeout_ticks; ctx->test_drop_member = oe.test_drop_member; ctx->test_no_morton = oe.test_no_morton; ctx->test_large_groups = oe.test_large_groups; }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_w), n_weights * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_w, ctx->w.data(), n_weights * sizeof(float), hipMemcpyHostToDevice);
     {
@@ -585,6 +594,9 @@ void ifd_destroy(ifd_ctx* ctx) {
     if (ctx->ws_mesh) (void)hipFree(ctx->ws_mesh);
     if (ctx->h_mesh_counts) (void)hipHostFree(ctx->h_mesh_counts);
     for (hipEvent_t ev : ctx->mesh_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipStream_t st : ctx->large_side) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : ctx->large_join) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->large_fork) (void)hipEventDestroy(ctx->large_fork);
     delete ctx;
 }
 
@@ -657,6 +669,93 @@ int ifd_encode_planes(ifd_ctx* ctx, const float* sel, const int32_t* t_per_cloud
     return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_encode_planes", e);
 }
 
+namespace {
+
+// Clouds of more than 1024 points take two launches per Adam step (occupancy gradient; then neighbour lists + repulsion + Adam), and a
+// launch ends with its slowest cloud: the list-step launch of 256 clouds on 256 CUs takes 187 us where ONE cloud's averages 79
+// (profiles/r06_large_k_launch_times.txt) - most CUs idle while the slowest clouds finish.  The batch therefore goes as G contiguous
+// groups on G streams (the caller's + side streams of the context), the launches enqueued step by step across the groups.  The steps
+// of a group depend on its own clouds only, and the groups drift apart: the CUs one group's list step leaves idle run another group's
+// occupancy workgroups.  Same kernels, same arithmetic per cloud: bit-identical to one group (tests).  Measured, K = 2048, 501 steps,
+// time per point over the persistent kernel's (profiles/r06_large_k_groups.txt): 256 clouds 1.51 -> 1.34 (G = 4), 512 1.41 -> 1.24
+// (G = 2), 1024 1.24 (2) / 1.20 (4), a file of 2304 1.30 -> 1.23 (4); groups of about one cloud per CU do best, more than four
+// never helped, and chaining the occupancy launches in a ring through events cost more than it ordered (1.77).
+int large_groups_of(const ifd_ctx* ctx, int B) {
+    if (ctx->test_large_groups > 0) return std::min(std::min(ctx->test_large_groups, LARGE_MAX_GROUPS), B);
+    if (B < 32) return 1;
+    if (B <= ctx->n_cu) return LARGE_MAX_GROUPS;
+    return std::max(2, std::min(LARGE_MAX_GROUPS, (B + ctx->n_cu / 2) / ctx->n_cu));
+}
+
+hipError_t large_optimize_in_groups(ifd_ctx* ctx, const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
+                                    const int32_t* lbpc, int B, int K, const OptArgs& a, hipStream_t s) {
+    const bool own = m == nullptr;
+    const int G = large_groups_of(ctx, B);
+    const int per = (B + G - 1) / G;
+    const size_t slice = (large_ws_bytes(per, K, own) + 255) & ~(size_t)255;
+    hipError_t e = ensure_ws(ctx, slice * G);
+    if (e != hipSuccess) return e;
+    if (G > 1) {
+        if (!ctx->large_fork && (e = hipEventCreateWithFlags(&ctx->large_fork, hipEventDisableTiming)) != hipSuccess) return e;
+        for (int g = 1; g < G; ++g) {
+            if (!ctx->large_side[g - 1] && (e = hipStreamCreateWithFlags(&ctx->large_side[g - 1], hipStreamNonBlocking)) != hipSuccess) return e;
+            if (!ctx->large_join[g - 1] && (e = hipEventCreateWithFlags(&ctx->large_join[g - 1], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if ((e = hipEventRecord(ctx->large_fork, s)) != hipSuccess) return e;
+    }
+    struct Group { int g0, Bg, parts; char* G; float *p, *m, *v, *loss; const int32_t* lb; const float* planes; void *f_ws, *list_ws; hipStream_t s; };
+    Group gr[LARGE_MAX_GROUPS];
+    int n_groups = 0;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t x) { if (x != hipSuccess && first == hipSuccess) first = x; };
+    const int ntiles = (K + 31) / 32, n_cu = std::max(8, ctx->n_cu);
+    for (int g = 0; g < G; ++g) {
+        Group& q = gr[g];
+        q.g0 = g * per; q.Bg = std::min(per, B - q.g0);
+        if (q.Bg <= 0) break;
+        ++n_groups;
+        const size_t o3 = (size_t)q.g0 * K * 3;
+        q.s = g == 0 ? s : ctx->large_side[g - 1];
+        q.G = static_cast<char*>(ctx->ws) + slice * g;
+        q.p = p + o3; q.planes = planes + (size_t)q.g0 * CLOUD_PLANE_FLOATS;
+        q.loss = loss ? loss + 2 * (size_t)q.g0 : nullptr; q.lb = lbpc ? lbpc + q.g0 : nullptr;
+        // one workgroup fills a CU; with fewer clouds than CUs a cloud's tiles are shared out over `parts` workgroups
+        q.parts = q.Bg >= n_cu ? 1 : std::min((ntiles + 7) / 8, std::max(1, n_cu / q.Bg));
+        if (g > 0) note(hipStreamWaitEvent(q.s, ctx->large_fork, 0));
+        note(large_f_prepare(q.G, q.Bg, K, own, &q.f_ws, q.s));
+        q.list_ws = large_list_ws(q.G, q.Bg, K, own);
+        if (own) {                                        // own moments behind G (large_ws_bytes), zeroed
+            q.m = reinterpret_cast<float*>(q.G + (size_t)q.Bg * K * 16);
+            q.v = q.m + (size_t)q.Bg * K * 3;
+            note(hipMemsetAsync(q.m, 0, (size_t)q.Bg * K * 3 * 4 * 2, q.s));
+        } else {
+            q.m = m + o3; q.v = v + o3;
+        }
+    }
+    for (int step = 0; step < a.steps && first == hipSuccess; ++step) {
+        const bool last = step == a.steps - 1;
+        for (int g = 0; g < n_groups; ++g) {
+            Group& q = gr[g];
+            note(launch_large_occupancy(a.precision, dec_img, q.planes, q.p, q.Bg, q.parts, K, q.lb, a.loss_batch, a.threshold,
+                                        (last && q.loss != nullptr) ? 1 : 0, q.G, a.dc, q.s));
+            note(launch_large_step(q.p, q.m, q.v, q.G, q.Bg, K, static_cast<const float*>(ctx->adam_tab), step, q.lb, a, last ? q.loss : nullptr,
+                                   q.f_ws, q.list_ws, ctx->d_counters, q.s));
+        }
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        Group& q = gr[g];
+        if (a.normalize && first == hipSuccess) note(launch_large_normalize(q.p, q.Bg, K, q.s));
+        if (g > 0) {                                      // (joined even after a failed launch: the caller's stream must not run ahead of a side stream)
+            hipError_t x = hipEventRecord(ctx->large_join[g - 1], q.s);
+            if (x == hipSuccess) x = hipStreamWaitEvent(s, ctx->large_join[g - 1], 0);
+            note(x);
+        }
+    }
+    return first;
+}
+
+}  // namespace
+
 int ifd_decode_ex(ifd_ctx* ctx, const float* planes, const float* p, int B, int K, int precision, float* logits, float* dlogit_dp,
                   void* stream) {
     if (!ctx) return IFD_ERR_ARG;
@@ -719,7 +818,7 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
         return fail(ctx, IFD_ERR_ARG, "ifd_optimize: precision must be 0 (f32 MFMA), 1 (bf16x6) or 2 (bf16x3)");
     a.precision = prm->precision;
     const bool large = K > MAXK;              // more points than one CU's LDS holds: two launches per step (optimize.hip)
-    hipError_t e = ensure_ws(ctx, large ? large_ws_bytes(B, K, m == nullptr) : optimize_ws_bytes(B));
+    hipError_t e = large ? hipSuccess : ensure_ws(ctx, optimize_ws_bytes(B));          // (large: per stream group, run_large_in_groups)
     if (e == hipSuccess) e = ensure_buf(&ctx->adam_tab, &ctx->adam_bytes, (size_t)(prm->steps > 0 ? prm->steps : 1) * 2 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_NOMEM, "ifd_optimize workspace", e);
     e = hipMemsetAsync(ctx->d_counters, 0, N_COUNTERS_DEV * sizeof(unsigned long long), static_cast<hipStream_t>(stream));
@@ -727,8 +826,8 @@ int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K, cons
     if (e == hipSuccess) e = launch_adam_table(static_cast<float*>(ctx->adam_tab), a.t0, a.steps, a.lr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ctx, IFD_ERR_HIP, "ifd_optimize memset / Adam table", e);
     if (large) {
-        e = launch_large_optimize(a.precision != 0 ? ctx->d_dec_img_bf : ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws,
-                                  ctx->d_counters, static_cast<const float*>(ctx->adam_tab), B, K, a, ctx->n_cu, static_cast<hipStream_t>(stream));
+        e = large_optimize_in_groups(ctx, a.precision != 0 ? ctx->d_dec_img_bf : ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud,
+                                     B, K, a, static_cast<hipStream_t>(stream));
         return e == hipSuccess ? IFD_OK : fail(ctx, IFD_ERR_HIP, "ifd_optimize launch (large clouds)", e);
     }
     e = launch_optimize(a.precision != 0 ? ctx->d_dec_img_bf : ctx->d_dec_img_opt, planes, p, m, v, loss, loss_batch_per_cloud, ctx->ws, ctx->d_counters,

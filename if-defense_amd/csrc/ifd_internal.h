@@ -90,9 +90,9 @@ hipError_t launch_normalize(float* p, int B, int K, hipStream_t s);
 // clouds of MAXK < K <= LARGE_MAXK optimised points: two launches per Adam step (optimize.hip, "large" section)
 size_t large_ws_bytes(int B, int K, bool own_moments);
 // dec_img: the image of a.precision (f32: the optimiser's copy; 1 / 2: the bf16 piece image)
-hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                                 const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
-                                 const float* adam_tab, int B, int K, const OptArgs& a, int n_cu, hipStream_t s);
+hipError_t launch_large_occupancy(int precision, const float* dec_img, const float* planes, const float* p, int B, int parts, int K,
+                                  const int32_t* loss_batch_per_cloud, int loss_batch, float thr, int want_loss, void* G, DecConst dc,
+                                  hipStream_t s);
 size_t large_list_bytes(int B, int K);        // certified neighbour lists of the launch-per-step path (0 beyond LARGE_LDS_MAXK points)
 void* large_list_ws(void* ws, int B, int K, bool own_moments);                                      // ... inside ws (nullptr beyond)
 size_t large_f_bytes(int B, int K);           // global repulsion accumulators of clouds beyond LARGE_LDS_MAXK points (0 below)

@@ -935,43 +935,18 @@ static void large_step_launch(float* p, float* m, float* v, const f32x4* G, int 
 // ws: [B][K] f32x4 occupancy gradients, then (m == nullptr) the two moment arrays, zeroed here, then large_f_bytes
 hipError_t launch_large_occupancy_bf(int prec, const float* dec_img, const float* planes, const float* p, int B, int parts, int K,
                                      const int32_t* lbpc, int loss_batch, float thr, int want_loss, f32x4* G, DecConst dc, hipStream_t s);
-hipError_t launch_large_optimize(const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
-                                 const int32_t* loss_batch_per_cloud, void* ws, unsigned long long* counters,
-                                 const float* adam_tab, int B, int K, const OptArgs& a, int n_cu, hipStream_t s) {
-    f32x4* G = static_cast<f32x4*>(ws);
-    void* f_ws = nullptr;
-    void* list_ws = large_list_ws(ws, B, K, m == nullptr);
-    {
-        hipError_t e = large_f_prepare(ws, B, K, m == nullptr, &f_ws, s);
-        if (e != hipSuccess) return e;
-    }
-    if (m == nullptr) {
-        m = reinterpret_cast<float*>(G + (size_t)B * K);
-        v = m + (size_t)B * K * 3;
-        hipError_t e = hipMemsetAsync(m, 0, (size_t)B * K * 3 * 4 * 2, s);
-        if (e != hipSuccess) return e;
-    }
-    const RepConst rc = {a.rep_radius, a.rep_h, a.rep_eps};
-    // one workgroup fills a CU (the persistent kernel's tile: 8 waves of 256 registers); with fewer clouds than CUs a cloud's
-    // (K / 32) tiles are shared out over `parts` workgroups of 8 waves
-    n_cu = max(8, n_cu);
-    const int parts = B >= n_cu ? 1 : min(((K + 31) / 32 + 7) / 8, max(1, n_cu / B));
-    for (int step = 0; step < a.steps; ++step) {
-        const int want_loss = (step == a.steps - 1 && loss != nullptr) ? 1 : 0;
-        if (a.precision != 0) {
-            hipError_t e = launch_large_occupancy_bf(a.precision, dec_img, planes, p, B, parts, K, loss_batch_per_cloud, a.loss_batch,
-                                                     a.threshold, want_loss, G, a.dc, s);
-            if (e != hipSuccess) return e;
-        } else {
-            hipLaunchKernelGGL(large_occupancy3_kernel<0>, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
-                               loss_batch_per_cloud, a.loss_batch, a.threshold, want_loss, G, a.dc);
-        }
-        large_step_launch(p, m, v, G, B, K, adam_tab, step, loss_batch_per_cloud, a, rc, (step == a.steps - 1) ? loss : nullptr,
-                          f_ws, list_ws, counters, s);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (a.normalize) hipLaunchKernelGGL(large_normalize_kernel, dim3(B), dim3(LARGE_THREADS), 0, s, p, K);
+// The occupancy half of a step of the launch-per-step path: the occupancy gradient of every point of B clouds into G ([B, K] f32x4),
+// in ifd_opt_params.precision's arithmetic (dec_img = the image of that precision).  One workgroup fills a CU (the persistent kernel's
+// tile: 8 waves of 256 registers); `parts` workgroups of 8 waves share a cloud's (K / 32) tiles.  The step loop is api.cpp's
+// (large_optimize_in_groups: stream groups, so that one group's occupancy launch fills the CUs another group's list step leaves idle).
+hipError_t launch_large_occupancy(int precision, const float* dec_img, const float* planes, const float* p, int B, int parts, int K,
+                                  const int32_t* loss_batch_per_cloud, int loss_batch, float thr, int want_loss, void* G, DecConst dc,
+                                  hipStream_t s) {
+    if (precision != 0)
+        return launch_large_occupancy_bf(precision, dec_img, planes, p, B, parts, K, loss_batch_per_cloud, loss_batch, thr, want_loss,
+                                         static_cast<f32x4*>(G), dc, s);
+    hipLaunchKernelGGL(large_occupancy3_kernel<0>, dim3(B, parts), dim3(OPT_THREADS), DEC_LDS, s, dec_img, planes, p, K,
+                       loss_batch_per_cloud, loss_batch, thr, want_loss, static_cast<f32x4*>(G), dc);
     return hipGetLastError();
 }
 

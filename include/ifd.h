@@ -233,7 +233,9 @@ typedef struct ifd_opt_params {
  * launches per Adam step (decoder gradient on the persistent kernel's tile, in the requested precision; exact 5-NN +
  * repulsion + Adam), same arithmetic.  Up to 4096 points the second launch keeps certified neighbour lists of its own
  * (bit-identical to the brute-force scan, which knn_scan_every_step selects and which clouds beyond 4096 points always
- * take); knn_reference_form applies at every size.  Counters of this path: [0] whole-cloud list builds (one per cloud
+ * take); knn_reference_form applies at every size.  Batches of 32 clouds and more go as up to four groups of clouds on streams
+ * of the context beside `stream` (a launch ends with its slowest cloud; the groups fill each other's idle CUs): forked from and
+ * joined into `stream`, so the call is ordered on `stream` like every other, and bit-identical to one group.  Counters of this path: [0] whole-cloud list builds (one per cloud
  * and call), [5] point-steps whose certificate did not hold and that were resolved by the exact query. */
 int ifd_optimize(ifd_ctx* ctx, const float* planes, float* p, int B, int K,
                  const ifd_opt_params* prm, const int32_t* loss_batch_per_cloud,

@@ -1,4 +1,5 @@
 """ifd_optimize on clouds of more than 1024 points (the two-launch-per-step path): time per point and step against the persistent kernel."""
+import hashlib
 import os
 import sys
 import time
@@ -22,13 +23,14 @@ for k in ks:
     planes = r.encode_inputs(prep["sel"], prep["t_per_cloud"])
     r.optimize_points(prep["init"][:8], planes[:8], rep_weight=500.0, steps=2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps, knn_scan_every_step=scan, precision=prec)
+    out = r.optimize_points(prep["init"], planes, rep_weight=500.0, steps=steps, knn_scan_every_step=scan, precision=prec)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    digest = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]
     c = r.counters()
     per = dt / (n * k * steps)
     base = base or per
-    print("K = %5d: %d clouds x %d steps in %.1f ms -> %.2f ns per point and step (%.2f x the first line)%s" % (
-        k, n, steps, dt * 1e3, per * 1e9, per / base,
+    print("K = %5d: %d clouds x %d steps in %.1f ms -> %.2f ns per point and step (%.2f x the first line) [points %s]%s" % (
+        k, n, steps, dt * 1e3, per * 1e9, per / base, digest,
         "" if k <= 1024 else "; %.1f list epochs per cloud, %.2f %% of the point-steps through the exact query" %
         (c["knn_rebuilds"] / float(n), 100.0 * c["knn_exact_evals"] / (float(n) * k * steps))))
     if k > 1024 and c["prof_cycles"][3]:          # a -DIFD_PROF build: cloud 0's phase cycles per (non-first) step

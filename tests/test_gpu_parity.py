@@ -468,6 +468,41 @@ def test_large_clouds_more_than_1024_points(restorer, golden, planes2, oracle_we
         assert abs(float(got.norm(dim=-1).max()) - 1.0) < 1e-5 and torch.isfinite(lv).all()
 
 
+def test_large_clouds_stream_groups_are_bit_identical_to_one_group(restorer, np_weights, monkeypatch):
+    """Clouds of more than 1024 points, 32 clouds and more per call: the batch goes as up to four groups on streams of the context
+    (api.cpp large_optimize_in_groups; a launch pair ends with its slowest cloud, the groups fill each other's idle CUs).  Same
+    kernels, same arithmetic per cloud: points, moments and losses bit for bit those of ONE group (a context created with the
+    measurement hook), for uneven groups, own and caller-held moments, per-cloud loss batches, and a second call on the same
+    context (the side streams are joined into the caller's)."""
+    import ifdefense_amd as I
+    import bench
+    B, K = 37, 1100                                              # groups of 10, 10, 10, 7
+    x = torch.from_numpy(bench.synth_clouds(B))
+    prep = restorer.prepare(x, restorer.sor(x), n_sel=600, n_opt=K, seed=5)
+    planes = restorer.encode_inputs(prep["sel"], prep["t_per_cloud"])
+    lb = torch.tensor([3 + (i % 5) for i in range(B)], dtype=torch.int32)
+    monkeypatch.setenv("IFD_ENABLE_TEST_HOOKS", "1")
+    monkeypatch.setenv("IFD_TEST_LARGE_GROUPS", "1")
+    one = I.Restorer(I.weights.pack_state_dict(np_weights), device="cuda:0")
+    monkeypatch.delenv("IFD_TEST_LARGE_GROUPS")
+    try:
+        for r_ in (restorer, restorer):                          # twice: the second call reuses the side streams and the workspace
+            got = r_.optimize_points(prep["init"], planes, rep_weight=500.0, steps=6, loss_batch=lb, normalize=True, return_state=True, return_loss=True)
+            ref = one.optimize_points(prep["init"], planes, rep_weight=500.0, steps=6, loss_batch=lb, normalize=True, return_state=True, return_loss=True)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1][0], ref[1][0]) and torch.equal(got[1][1], ref[1][1]) and torch.equal(got[2], ref[2])
+        # caller-held moments carried across two calls (t0 > 0), no normalisation
+        a1 = restorer.optimize_points(prep["init"], planes, rep_weight=500.0, steps=3, normalize=False, return_state=True)
+        a2 = restorer.optimize_points(a1[0], planes, rep_weight=500.0, steps=3, normalize=False, state=a1[1], return_state=True)
+        b1 = one.optimize_points(prep["init"], planes, rep_weight=500.0, steps=3, normalize=False, return_state=True)
+        b2 = one.optimize_points(b1[0], planes, rep_weight=500.0, steps=3, normalize=False, state=b1[1], return_state=True)
+        assert torch.equal(a2[0], b2[0]) and torch.equal(a2[1][0], b2[1][0]) and torch.equal(a2[1][1], b2[1][1])
+        whole = restorer.optimize_points(prep["init"], planes, rep_weight=500.0, steps=6, normalize=False)
+        assert torch.equal(whole, a2[0])                          # (and the cut run equals the uncut one)
+        assert float(got[0].norm(dim=-1).max()) == pytest.approx(1.0, abs=1e-5) and bool(torch.isfinite(got[0]).all())
+    finally:
+        one.close()
+
+
 def test_large_cloud_lists_equal_exact_scan(restorer, golden):
     """Round 6: 1025 ... 4096 optimised points keep certified neighbour lists too (optimize.hip large_step_lists_kernel): per-point
     lists in global memory, a certificate per point and step, an exact wave-cooperative query (and a new list) for every point whose
