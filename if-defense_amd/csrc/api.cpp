@@ -680,9 +680,9 @@ namespace {
 // time per point over the persistent kernel's (profiles/r06_large_k_groups.txt): 256 clouds 1.51 -> 1.34 (G = 4), 512 1.41 -> 1.24
 // (G = 2), 1024 1.24 (2) / 1.20 (4), a file of 2304 1.30 -> 1.23 (4); groups of about one cloud per CU do best, more than four
 // never helped, and chaining the occupancy launches in a ring through events cost more than it ordered (1.77).
-int large_groups_of(const ifd_ctx* ctx, int B) {
+int large_groups_of(const ifd_ctx* ctx, int B, bool lists) {
     if (ctx->test_large_groups > 0) return std::min(std::min(ctx->test_large_groups, LARGE_MAX_GROUPS), B);
-    if (B < 32) return 1;
+    if (B < 32 || !lists) return 1;          // (the brute-force step kernels cost every cloud the same: nothing to fill)
     if (B <= ctx->n_cu) return LARGE_MAX_GROUPS;
     return std::max(2, std::min(LARGE_MAX_GROUPS, (B + ctx->n_cu / 2) / ctx->n_cu));
 }
@@ -690,7 +690,7 @@ int large_groups_of(const ifd_ctx* ctx, int B) {
 hipError_t large_optimize_in_groups(ifd_ctx* ctx, const float* dec_img, const float* planes, float* p, float* m, float* v, float* loss,
                                     const int32_t* lbpc, int B, int K, const OptArgs& a, hipStream_t s) {
     const bool own = m == nullptr;
-    const int G = large_groups_of(ctx, B);
+    const int G = large_groups_of(ctx, B, K <= LARGE_LDS_MAXK && a.knn_scan_every_step == 0);
     const int per = (B + G - 1) / G;
     const size_t slice = (large_ws_bytes(per, K, own) + 255) & ~(size_t)255;
     hipError_t e = ensure_ws(ctx, slice * G);
