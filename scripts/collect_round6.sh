@@ -28,4 +28,5 @@ python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
 python bench.py --streamed --no-extras --no-cpu-baseline > gpurun_out/r06_bench_streamed.json 2>/dev/null
 IFD_LIB=$R/if-defense_amd/csrc/libifd_v_prof.so timeout 300 python scripts/time_large_k.py 256 1024 2048 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_time_large_k_prof.txt
 (timeout 300 python scripts/time_large_k.py 256 1024 2048 4096; IFD_LARGE_STEPS=501 timeout 300 python scripts/time_large_k.py 256 1024 2048; IFD_LARGE_SCAN=1 timeout 300 python scripts/time_large_k.py 256 1024 2048 4096) 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_time_large_k.txt
+bash scripts/large_k_groups.sh > gpurun_out/r06_large_k_groups.txt 2>&1
 cut -c1-300 gpurun_out/r06_bench.json
